@@ -1,0 +1,201 @@
+/* rtmi.h -- C ABI of the MI355X (gfx950) path-tracing core.
+ *
+ * Drop-in boundary for the per-pixel hot path of the lukeovalle/raytracing renderer:
+ * camera-ray generation, ray/scene intersection and the Monte-Carlo bounce loop with 60-bin
+ * spectral weights. A host program (the reference's Rust host through an FFI shim, or the C++
+ * host in this repository) flattens its Camera and Scene into the plain structs below and
+ * calls these entry points. No C++ or torch types cross this boundary. Citations are
+ * file:line in the reference repository.
+ *
+ * Conventions
+ *  - every function returns 0 (RTMI_OK) or a negative rtmi_status; rtmi_last_error() gives the
+ *    message of the calling thread's last failure; nothing aborts or throws across the ABI;
+ *  - the caller owns every input array (copied during the call) and every output buffer;
+ *  - a context is bound to one GPU; one call at a time per context; distinct contexts may be
+ *    used from different threads or processes (one process per GPU is the intended model);
+ *  - "host" pointers are ordinary memory, "device" pointers are HIP device memory of the
+ *    context's GPU; `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *  - images are row-major with y = 0 at the top (src/camera.rs:26-29).
+ */
+#ifndef RTMI_H
+#define RTMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTMI_NBINS 60          /* SampledSpectrum = 60 bins over 400..700 nm (src/spectrum/mod.rs:262-265) */
+#define RTMI_MISS 0xFFFFFFFFu
+#define RTMI_MAX_DEPTH 32      /* longest path (ray casts per path) the kernels carry state for */
+
+typedef enum {
+  RTMI_OK = 0, RTMI_BAD_ARG = -1, RTMI_NO_DEVICE = -2, RTMI_OOM = -3, RTMI_HIP_ERROR = -4, RTMI_UNSUPPORTED = -5
+} rtmi_status;
+
+/* enum Shape (src/shapes/shape.rs:34-39); BoxAABB is never built by any loader and is not carried */
+enum { RTMI_OBJ_SPHERE = 0, RTMI_OBJ_TRIANGLE = 1, RTMI_OBJ_MODEL = 2 };
+/* enum Type (src/material.rs:5-9) */
+enum { RTMI_MAT_EMITTER = 0, RTMI_MAT_LAMBERTIAN = 1, RTMI_MAT_SPECULAR = 2 };
+/* which Option<SampledSpectrum> fields of Material are Some (src/material.rs:15-19) */
+enum { RTMI_HAS_AMBIENT = 1, RTMI_HAS_EMITTED = 2, RTMI_HAS_DIFFUSED = 4, RTMI_HAS_SPECULAR = 8 };
+/* Hit rule inside a mesh. FIRST_INDEX is the reference's behaviour (first triangle in file order
+ * that the ray hits, src/shapes/model_obj.rs:80-84); NEAREST is smallest t, ties to the smaller index. */
+enum { RTMI_HIT_FIRST_INDEX = 0, RTMI_HIT_NEAREST = 1 };
+/* enum Integrator (src/integrators/integrator.rs:145-151) */
+enum { RTMI_INT_RANDOM_WALK = 0, RTMI_INT_ALBEDO = 1, RTMI_INT_NORMAL = 2 };
+/* enum SpectrumType (src/spectrum/mod.rs:8-11) */
+enum { RTMI_SPEC_REFLECTANCE = 0, RTMI_SPEC_ILLUMINANT = 1 };
+/* rtmi_render_params.flags */
+enum {
+  RTMI_FLAG_TIME_KERNELS = 1,    /* bracket every closest-hit kernel with HIP events (adds host syncs) */
+  RTMI_FLAG_COUNT_TRAVERSAL = 2, /* count BVH nodes visited and triangles tested (slower kernel variant) */
+  RTMI_FLAG_NO_REGENERATION = 4  /* one queue chain per batch, no refilling of finished path slots */
+};
+
+/* Ray (src/geometry/ray.rs:5-10): direction must be normalised; max_t is always +inf on this path */
+typedef struct { double o[3]; double d[3]; } rtmi_ray;
+
+/* Intersection (src/shapes/common.rs:9-17) without the by-value shape copy */
+typedef struct {
+  uint32_t obj;   /* index into rtmi_scene_desc.objects, RTMI_MISS when nothing was hit */
+  uint32_t prim;  /* triangle index inside a model, in file order; 0 for spheres and lone triangles */
+  double t;       /* as the reference reports it; spheres: along the re-normalised local ray (src/shapes/sphere.rs:101) */
+  double p[3];    /* world-space hit point */
+  double n[3];    /* geometric outward normal, not turned towards the ray */
+} rtmi_hit;
+
+/* one entry of Scene::objetos (src/scene.rs:7-9), in scene order */
+typedef struct {
+  uint32_t kind;      /* RTMI_OBJ_* */
+  uint32_t first;     /* first sphere (kind SPHERE) or first triangle (TRIANGLE, MODEL) */
+  uint32_t count;     /* 1, or the number of triangles of a model (file order) */
+  uint32_t material;  /* index into materials */
+} rtmi_object;
+
+/* Sphere (src/shapes/sphere.rs:8-14): radius at the local origin under a row-major 3x4 local->world map */
+typedef struct { double l2w[12]; double radius; } rtmi_sphere;
+
+/* Triangle (src/shapes/triangle.rs:9-15) with the identity local->world map every loader uses
+ * (src/scene_config.rs:189, src/shapes/model_obj.rs:54): world-space vertices, winding gives the normal */
+typedef struct { double v[9]; } rtmi_triangle;
+
+/* Material (src/material.rs:12-23); specular_coefficient / optical_density are never read on this path */
+typedef struct {
+  uint32_t type;     /* RTMI_MAT_* */
+  uint32_t present;  /* RTMI_HAS_* bits */
+  float ambient[RTMI_NBINS], emitted[RTMI_NBINS], diffused[RTMI_NBINS], specular[RTMI_NBINS];
+} rtmi_material;
+
+typedef struct {
+  const rtmi_object* objects; uint32_t n_objects;
+  const rtmi_sphere* spheres; uint32_t n_spheres;
+  const rtmi_triangle* triangles; uint32_t n_triangles;
+  const rtmi_material* materials; uint32_t n_materials;
+  uint32_t hit_rule;  /* RTMI_HIT_* */
+  uint32_t reserved;  /* 0 */
+} rtmi_scene_desc;
+
+/* Camera (src/camera.rs:4-9): focus and the screen rectangle (p1 top-left, p2 top-right,
+ * p3 bottom-left, p4 bottom-right) */
+typedef struct { double focus[3], p1[3], p2[3], p3[3], p4[3]; uint32_t width, height; } rtmi_camera;
+
+/* What SamplerIntegrator::render is asked to do (src/integrators/integrator.rs:17-118) plus the
+ * partition that replaces the tile thread pool (src/parallel.rs). */
+typedef struct {
+  uint32_t integrator;  /* RTMI_INT_* */
+  uint32_t max_depth;   /* RandomWalkIntegrator depth (src/main.rs:93); ignored by the AOV integrators */
+  uint32_t spp;         /* total_samples(): the divisor of the Monte-Carlo mean */
+  uint32_t flags;       /* RTMI_FLAG_* */
+  uint64_t seed;        /* Philox key */
+  uint32_t sample_begin, sample_end;  /* sample-range partition: this call renders samples [begin,end); end==0 -> [0,spp) */
+  uint32_t tile_rank, tile_world;     /* tile partition: tile k (x-major as src/integrators/integrator.rs:50) is rendered iff k % world == rank; world==0 -> all */
+  uint32_t tile_size;                 /* 0 -> 16 (src/integrators/integrator.rs:39) */
+  uint32_t reserved;                  /* 0 */
+} rtmi_render_params;
+
+typedef struct {
+  uint64_t segments;       /* closest-hit queries issued by the integrator (primary + bounce rays) */
+  uint64_t paths;          /* (pixel, sample) pairs evaluated */
+  uint64_t nodes_visited;  /* with RTMI_FLAG_COUNT_TRAVERSAL */
+  uint64_t prims_tested;   /* with RTMI_FLAG_COUNT_TRAVERSAL: mesh triangles put through Moller-Trumbore */
+  double ms_total;         /* host wall time of the call */
+  double ms_kernels;       /* with RTMI_FLAG_TIME_KERNELS: device time summed over closest-hit kernel launches */
+  uint32_t launches;       /* closest-hit kernel launches */
+  uint32_t batches;
+} rtmi_stats;
+
+typedef struct {
+  uint32_t n_nodes, max_depth, n_mesh_triangles, n_spectra;
+  uint64_t node_bytes, triangle_bytes;
+} rtmi_scene_info;
+
+typedef struct rtmi_ctx rtmi_ctx;
+typedef struct rtmi_scene rtmi_scene;
+
+/* ---- context ---------------------------------------------------------------------------- */
+
+/* Binds a context to GPU `device_id` (-1 = the current HIP device). Replaces nothing in the
+ * reference: the reference has no device. max_batch_paths caps the path slots (and so the
+ * memory) one render batch uses; 0 = default. */
+int rtmi_ctx_create(int device_id, uint64_t max_batch_paths, rtmi_ctx** out);
+void rtmi_ctx_destroy(rtmi_ctx* ctx);
+/* Message of the calling thread's most recent failed call ("" if none). */
+const char* rtmi_last_error(void);
+/* Library version string, "rtmi <version> gfx950". */
+const char* rtmi_version(void);
+
+/* ---- spectra: SampledSpectrum::{init, from_RGB, to_XYZ} and XYZ_to_RGB
+ *      (src/spectrum/mod.rs:386-522, 525-581, 590-609, 630-636), host side, used at load time */
+int rtmi_spectrum_from_rgb(float r, float g, float b, int type, float out[RTMI_NBINS]);
+int rtmi_spectrum_to_xyz(const float spectrum[RTMI_NBINS], float xyz[3]);
+int rtmi_xyz_to_rgb(const float xyz[3], float rgb[3]);
+/* The 60-bin CIE matching curves the kernels use (src/spectrum/mod.rs:268-270 after init()). */
+int rtmi_spectrum_cie_tables(float x[RTMI_NBINS], float y[RTMI_NBINS], float z[RTMI_NBINS]);
+
+/* ---- camera: Camera::new (src/camera.rs:19-51) ------------------------------------------- */
+int rtmi_camera_new(const double focus[3], double focal_distance, double field_of_view_deg,
+                    const double rotation_rpy[3], uint32_t width, uint32_t height, rtmi_camera* out);
+/* Camera::get_ray (src/camera.rs:71-85), host side, for callers that build their own ray sets. */
+int rtmi_camera_get_ray(const rtmi_camera* cam, double i, double j, rtmi_ray* out);
+
+/* ---- scene: what Scene::add_shape builds (src/scene.rs:18-21), flattened and uploaded ----- */
+int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* desc, rtmi_scene** out);
+void rtmi_scene_destroy(rtmi_scene* scene);
+int rtmi_scene_get_info(const rtmi_scene* scene, rtmi_scene_info* out);
+
+/* ---- Scene::intersect_ray (src/scene.rs:135-150) over a batch of rays --------------------- */
+int rtmi_intersect_batch(rtmi_scene* scene, const rtmi_ray* host_rays, size_t n, rtmi_hit* host_hits, rtmi_stats* stats);
+/* Same, rays and hits already in device memory; asynchronous on `stream`. */
+int rtmi_intersect_batch_device(rtmi_scene* scene, const rtmi_ray* dev_rays, size_t n, rtmi_hit* dev_hits, void* stream);
+
+/* ---- SamplerIntegrator::incident_light (src/integrators/random_walk.rs:49-75, albedo.rs:46-71,
+ *      normal.rs:45-63) along caller-supplied rays. Ray i draws its random numbers from the
+ *      Philox counter (pixel_base + i, sample_index, bounce). Output: n x 60 spectra (host). */
+int rtmi_trace_batch(rtmi_scene* scene, const rtmi_ray* host_rays, size_t n, uint32_t integrator, uint32_t max_depth,
+                     uint64_t seed, uint32_t pixel_base, uint32_t sample_index, float* host_spectra, rtmi_stats* stats);
+
+/* ---- SamplerIntegrator::render (src/integrators/integrator.rs:30-118) --------------------- */
+/* Whole render on one GPU. host_rgb8: W*H*3 bytes (gamma 1/2.2, `(256*v) as u8`, :80-90).
+ * host_xyz (optional): W*H*3 floats, the mean CIE XYZ per pixel before tone mapping. */
+int rtmi_render(rtmi_scene* scene, const rtmi_camera* cam, const rtmi_render_params* params,
+                uint8_t* host_rgb8, float* host_xyz, rtmi_stats* stats);
+/* The same work for this call's share of the samples/tiles only: adds the per-pixel SUM of the
+ * samples' CIE XYZ into dev_xyz_sum (W*H*3 floats, device). Ranks of a multi-GPU job each call
+ * this, sum (sample partition) or merge (tile partition) their buffers with one collective, and
+ * finish with rtmi_tonemap. Asynchronous on `stream` unless RTMI_FLAG_TIME_KERNELS is set. */
+int rtmi_render_accumulate(rtmi_scene* scene, const rtmi_camera* cam, const rtmi_render_params* params,
+                           float* dev_xyz_sum, void* stream, rtmi_stats* stats);
+/* Fills *stats with the counters of the last render_accumulate on `scene` once its stream work
+ * has completed (synchronises the stream). */
+int rtmi_render_collect_stats(rtmi_scene* scene, void* stream, rtmi_stats* stats);
+/* mean = sum / spp, XYZ -> RGB, clamp, gamma, u8 (src/integrators/integrator.rs:79-90). */
+int rtmi_tonemap(rtmi_ctx* ctx, const float* dev_xyz_sum, uint32_t spp, uint32_t width, uint32_t height,
+                 uint8_t* dev_rgb8, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,66 @@
+// rt_kernels.h -- launch interface between the host runtime (rtmi_api.cpp) and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_types.h"
+#include "spectrum.h"
+
+namespace rtmi {
+
+// Path-state queue, structure of arrays (one element per path slot, coalesced per wave).
+struct PathQueue {
+  double* ox; double* oy; double* oz;
+  double* dx; double* dy; double* dz;
+  uint32_t* pixel;        // y * width + x : Philox counter word 0
+  uint32_t* sample;       // Philox counter word 1
+  uint32_t* slot;         // where this path's contribution goes
+  uint32_t* remaining;    // ray casts the path may still make (the reference's `iteraciones`)
+  uint4* chain0;          // spectrum-table rows picked up at hits 0..15, one byte each
+  uint4* chain1;          // hits 16..31
+};
+
+constexpr int kBlock = 256;            // 4 waves of 64
+constexpr uint32_t kPixelBlock = 8;    // a wave covers an 8x8 pixel block of its tile
+
+// One batch of primary paths: samples [sample0, sample0+n_samples) of the pixels of a run of
+// tiles. Path slot = sample_local * n_local_pixels + local_pixel.
+struct BatchDesc {
+  DevCamera cam;
+  const uint32_t* tile_list;   // tile ids (x-major) this batch covers, device memory
+  uint32_t n_tiles;            // entries of tile_list used
+  uint32_t tile_size;          // multiple of 8
+  uint32_t tiles_y;            // tiles per image column
+  uint32_t n_local_pixels;     // n_tiles * tile_size^2 (includes pixels clipped off the image)
+  uint32_t sample0, n_samples;
+  uint32_t integrator, max_depth;
+  uint64_t seed;
+  // caller-supplied rays instead of camera rays (rtmi_trace_batch): 6 doubles each, device memory
+  const double* rays;
+  uint32_t n_rays, pixel_base;
+};
+
+struct TraceOutputs {
+  float* contrib_x; float* contrib_y; float* contrib_z;  // per path slot, CIE XYZ of the sample
+  float* spectra;                                        // optional: per path slot, 60 bins
+};
+
+struct TraversalCounters { unsigned long long nodes, prims; };
+
+void upload_constants(const SpectrumTables& t);
+
+// Bounce 0: generates the camera rays of the batch (or reads caller rays), finds the closest
+// hit, shades, and appends surviving paths to `out` (count in *out_count).
+void launch_primary(const DevScene& sc, const BatchDesc& b, PathQueue out, uint32_t* out_count, TraceOutputs o,
+                    TraversalCounters* counters, hipStream_t s);
+// Bounce k > 0: consumes *in_count (<= max_in) paths from `in`.
+void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const uint32_t* in_count, uint32_t max_in,
+                   PathQueue out, uint32_t* out_count, TraceOutputs o, TraversalCounters* counters, hipStream_t s);
+// rays: n x {o[3], d[3]} doubles; hits: n x rtmi_hit (64 bytes); both device memory.
+void launch_intersect(const DevScene& sc, const void* rays, size_t n, void* hits, TraversalCounters* counters, hipStream_t s);
+// Adds the batch's per-slot contributions into the per-pixel sums, in sample order.
+void launch_resolve(const BatchDesc& b, TraceOutputs o, float* xyz_sum, hipStream_t s);
+// *total += counts[0] + ... + counts[n-1]
+void launch_sum_counts(const uint32_t* counts, uint32_t n, unsigned long long* total, hipStream_t s);
+void launch_tonemap(const float* xyz_sum, uint32_t spp, uint32_t n_pixels, uint8_t* rgb8, hipStream_t s);
+
+}  // namespace rtmi

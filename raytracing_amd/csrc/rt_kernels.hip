@@ -1,0 +1,689 @@
+// rt_kernels.hip -- gfx950 kernels of the path-tracing hot path.
+//
+// Wavefront path tracing: one kernel launch per bounce. A launch takes every path of the
+// current queue through closest-hit + material shading and appends the paths that continue to
+// the next queue with one wave-wide ballot and one atomic per wave (no megakernel, no
+// recursion). Geometry arithmetic is binary64 like the reference's; spectra are binary32.
+// A path does not carry a 60-bin throughput: it records, per hit, which spectrum-table row
+// it picked up (one byte), and the 60-bin product is formed once, when the path reaches an
+// emitter, in the reference's multiplication order.
+//
+// Citations are file:line in the reference repository.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+
+#include "rt_kernels.h"
+
+// Products and sums stay separately rounded in this file, as in the reference's (unfused)
+// binary64/binary32 arithmetic: a ray through an edge or a vertex, a grazing sphere hit and
+// every 60-bin product then decide and round exactly as the reference does. Only the BVH box
+// test, which is conservative by construction, asks for fused multiply-adds explicitly.
+#ifndef RT_ALLOW_FUSION
+#pragma clang fp contract(off)
+#endif
+
+namespace rtmi {
+
+// 60-bin CIE curves, to_XYZ scale and Smits reflectance bases (src/spectrum/mod.rs:268-279)
+__constant__ float c_cie[3][RT_NBINS];
+__constant__ float c_smits_refl[7][RT_NBINS];
+__constant__ float c_xyz_scale;
+
+void upload_constants(const SpectrumTables& t) {
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_cie), t.cie, sizeof t.cie);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_smits_refl), t.smits[0], sizeof t.smits[0]);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_xyz_scale), &t.xyz_scale, sizeof(float));
+}
+
+namespace {
+
+// ------------------------------------------------------------------------------- vectors
+
+struct V3 { double x, y, z; };
+
+__device__ __forceinline__ V3 mk(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator/(V3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ V3 normalize(V3 a) { return a / sqrt(dot(a, a)); }  // Ray::new, src/geometry/ray.rs:16
+__device__ __forceinline__ V3 ld3(const double* p) { return mk(p[0], p[1], p[2]); }
+
+// row-major 3x4 affine map applied to a point / a vector / transposed linear part to a vector
+__device__ __forceinline__ V3 xf_vec(const double* m, V3 v) {
+  return mk((m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[4] * v.x + m[5] * v.y) + m[6] * v.z,
+            (m[8] * v.x + m[9] * v.y) + m[10] * v.z);
+}
+__device__ __forceinline__ V3 xf_pt(const double* m, V3 p) {
+  V3 r = xf_vec(m, p);
+  return mk(r.x + m[3], r.y + m[7], r.z + m[11]);
+}
+__device__ __forceinline__ V3 xf_vec_t(const double* m, V3 v) {
+  return mk((m[0] * v.x + m[4] * v.y) + m[8] * v.z, (m[1] * v.x + m[5] * v.y) + m[9] * v.z,
+            (m[2] * v.x + m[6] * v.y) + m[10] * v.z);
+}
+
+// ------------------------------------------------------------------------------- Philox4x32-10
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// two uniforms in [0,1) with 53 random bits each, counter = (pixel, sample, bounce, stream)
+__device__ __forceinline__ void uniform_pair(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t bounce,
+                                             uint32_t stream, double& u0, double& u1) {
+  uint32_t r[4];
+  philox4x32_10(pixel, sample, bounce, stream, uint32_t(seed), uint32_t(seed >> 32), r);
+  const uint64_t a = (uint64_t(r[1]) << 32) | r[0], b = (uint64_t(r[3]) << 32) | r[2];
+  u0 = double(a >> 11) * 0x1.0p-53;
+  u1 = double(b >> 11) * 0x1.0p-53;
+}
+
+// ------------------------------------------------------------------------------- primitives
+
+// Moller-Trumbore, two-sided, inclusive edges, t >= 0 (src/geometry/mod.rs:16-80; same
+// rejection order and thresholds).
+__device__ __forceinline__ bool moller_trumbore(V3 v0, V3 v1, V3 v2, V3 o, V3 d, double& t_out) {
+  const V3 e1 = v1 - v0, e2 = v2 - v0, tv = o - v0;
+  const V3 p = cross(d, e2), q = cross(tv, e1);
+  const double det = dot(p, e1);
+  if (fabs(det) < 1e-10) return false;
+  const double inv = 1.0 / det;
+  const double t = inv * dot(q, e2);
+  if (t < 0.0) return false;
+  const double u = inv * dot(p, tv);
+  if (!(u >= 0.0 && u <= 1.0)) return false;
+  const double w = inv * dot(q, d);
+  if (w < 0.0 || u + w > 1.0) return false;
+  t_out = t;
+  return true;
+}
+
+// Triangle::intersect under the identity map every loader uses (src/shapes/triangle.rs:73-97).
+// `dn` is the ray direction after the reference's re-normalisation of the "local" ray
+// (src/geometry/ray.rs:45). Returns Moller-Trumbore's t (for the hit point) and the t the
+// reference reports, t / |n| with n the flat unit normal (src/shapes/triangle.rs:30,92).
+__device__ __forceinline__ bool triangle_hit(V3 v0, V3 v1, V3 v2, V3 o, V3 dn, double& t_raw, double& t_reported) {
+  double t;
+  if (!moller_trumbore(v0, v1, v2, o, dn, t)) return false;
+  const V3 n = normalize(cross(v1 - v0, v2 - v0));
+  t_raw = t;
+  t_reported = t / sqrt(dot(n, n));
+  return true;
+}
+
+// Sphere under an affine map (src/shapes/sphere.rs:50-103). t is measured along the
+// re-normalised local ray, as the reference reports it.
+__device__ __forceinline__ bool sphere_t(const DevSphere& s, V3 o, V3 d, double& t_out) {
+  const V3 lo = xf_pt(s.w2l, o);
+  const V3 ld = normalize(xf_vec(s.w2l, d));
+  const double h = dot(ld, lo);
+  const double c = dot(lo, lo) - s.radius * s.radius;
+  const double disc = h * h - c;
+  if (disc < 0.0) return false;
+  const double sq = sqrt(disc);
+  const double t1 = -h - sq, t2 = -h + sq;
+  if (t2 < 0.0) return false;
+  t_out = t1 < 0.0 ? t2 : t1;
+  return true;
+}
+
+// Box test in binary64 against a binary32 box that was rounded outward and padded at build
+// time. NaNs from 0 * inf drop out of fmin/fmax, which only makes the test more permissive.
+__device__ __forceinline__ bool slab(const float* lo, const float* hi, V3 invd, V3 oid, double tmax, double& tnear) {
+  const double ax = fma(double(lo[0]), invd.x, -oid.x), bx = fma(double(hi[0]), invd.x, -oid.x);
+  const double ay = fma(double(lo[1]), invd.y, -oid.y), by = fma(double(hi[1]), invd.y, -oid.y);
+  const double az = fma(double(lo[2]), invd.z, -oid.z), bz = fma(double(hi[2]), invd.z, -oid.z);
+  const double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), 0.0));
+  const double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), tmax));
+  tnear = tn;
+  return tn <= tf;
+}
+
+struct MeshHit { double t, t_raw; uint32_t index; uint32_t slot; };
+
+// Closest hit inside one mesh through its BVH. RULE = RT_HIT_FIRST_INDEX returns the hit
+// triangle with the smallest file-order index (what the reference's linear scan returns,
+// src/shapes/model_obj.rs:80-84): subtrees whose smallest index cannot beat the current
+// winner are skipped, distance never prunes. RULE = RT_HIT_NEAREST returns the smallest t,
+// ties to the smaller index. The traversal stack lives in LDS, one column per lane.
+template <int RULE, bool COUNT>
+__device__ __forceinline__ bool mesh_closest(const BvhNode* __restrict__ nodes, const DevMeshTri* __restrict__ tris,
+                                             V3 o, V3 d, uint32_t* stack, MeshHit& best, uint32_t& n_nodes,
+                                             uint32_t& n_prims) {
+  const V3 invd = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+  const V3 oid = mk(o.x * invd.x, o.y * invd.y, o.z * invd.z);
+  best.t = INFINITY; best.t_raw = 0.0; best.index = RT_MISS; best.slot = 0;
+  uint32_t cur = 0;
+  int sp = 0;
+  for (;;) {
+    if (cur & RT_LEAF_FLAG) {
+      const uint32_t first = (cur & ~RT_LEAF_FLAG) >> 4, cnt = cur & 15u;
+      for (uint32_t i = 0; i < cnt; ++i) {
+        const DevMeshTri* tp = tris + first + i;
+        const uint32_t index = tp->index;
+        if (RULE == RT_HIT_FIRST_INDEX && index >= best.index) break;  // leaf is sorted by index
+        const double2* q = reinterpret_cast<const double2*>(tp->v);
+        const double2 a = q[0], b = q[1], c = q[2], e = q[3];
+        const double last = tp->v[8];
+        if (COUNT) ++n_prims;
+        double t_raw, t;
+        if (triangle_hit(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), mk(e.x, e.y, last), o, d, t_raw, t)) {
+          if (RULE == RT_HIT_FIRST_INDEX) {
+            best.t = t; best.t_raw = t_raw; best.index = index; best.slot = first + i;
+            break;
+          } else if (t < best.t || (t == best.t && index < best.index)) {
+            best.t = t; best.t_raw = t_raw; best.index = index; best.slot = first + i;
+          }
+        }
+      }
+      if (sp == 0) break;
+      cur = stack[(--sp) * kBlock];
+      continue;
+    }
+    const uint4* np = reinterpret_cast<const uint4*>(nodes + cur);
+    const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+    if (COUNT) ++n_nodes;
+    const float lo0[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
+    const float hi0[3] = {__uint_as_float(w0.w), __uint_as_float(w1.x), __uint_as_float(w1.y)};
+    const float lo1[3] = {__uint_as_float(w1.z), __uint_as_float(w1.w), __uint_as_float(w2.x)};
+    const float hi1[3] = {__uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w)};
+    const uint32_t ref0 = w3.x, ref1 = w3.y, min0 = w3.z, min1 = w3.w;
+    const double tmax = RULE == RT_HIT_NEAREST ? best.t : INFINITY;
+    double tn0, tn1;
+    bool h0 = ref0 != RT_REF_NONE && slab(lo0, hi0, invd, oid, tmax, tn0);
+    bool h1 = ref1 != RT_REF_NONE && slab(lo1, hi1, invd, oid, tmax, tn1);
+    if (RULE == RT_HIT_FIRST_INDEX) { h0 = h0 && min0 < best.index; h1 = h1 && min1 < best.index; }
+    if (h0 && h1) {
+      const bool swap = RULE == RT_HIT_FIRST_INDEX ? (min1 < min0) : (tn1 < tn0);
+      stack[(sp++) * kBlock] = swap ? ref0 : ref1;
+      cur = swap ? ref1 : ref0;
+    } else if (h0) {
+      cur = ref0;
+    } else if (h1) {
+      cur = ref1;
+    } else {
+      if (sp == 0) break;
+      cur = stack[(--sp) * kBlock];
+    }
+  }
+  return best.index != RT_MISS;
+}
+
+struct Hit {
+  uint32_t obj, prim;
+  double t;
+  V3 p, n;
+};
+
+// Scene::intersect_ray (src/scene.rs:135-150): closest over the object list in scene order,
+// strict '<' so the earlier object keeps a tie. The hit point and normal are formed once,
+// for the winner only.
+template <int RULE, bool COUNT>
+__device__ __forceinline__ bool closest_hit(const DevScene& sc, V3 o, V3 d, uint32_t* stack, Hit& hit,
+                                            uint32_t& n_nodes, uint32_t& n_prims) {
+  bool found = false;
+  double best_t = 0.0, best_raw = 0.0;
+  uint32_t best_obj = 0, best_prim = 0, best_slot = 0;
+  const V3 dn = normalize(d);  // what `identity.inverse() * ray` leaves of the direction (src/geometry/ray.rs:45)
+  for (uint32_t i = 0; i < sc.n_objects; ++i) {
+    const DevObject ob = sc.objects[i];
+    double t, t_raw = 0.0;
+    uint32_t prim = 0, slot = 0;
+    bool ok;
+    if (ob.kind == RT_OBJ_SPHERE) {
+      ok = sphere_t(sc.spheres[ob.first], o, d, t);
+    } else if (ob.kind == RT_OBJ_TRIANGLE) {
+      const DevTopTri& tr = sc.top_tris[ob.first];
+      ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, t_raw, t);
+    } else {
+      MeshHit mh;
+      ok = mesh_closest<RULE, COUNT>(sc.nodes + ob.root, sc.mesh_tris + ob.first, o, dn, stack, mh, n_nodes, n_prims);
+      t = mh.t; t_raw = mh.t_raw; prim = mh.index; slot = mh.slot;
+    }
+    if (ok && (!found || t < best_t)) {
+      found = true; best_t = t; best_raw = t_raw; best_obj = i; best_prim = prim; best_slot = slot;
+    }
+  }
+  if (!found) return false;
+  const DevObject ob = sc.objects[best_obj];
+  hit.obj = best_obj; hit.prim = best_prim; hit.t = best_t;
+  if (ob.kind == RT_OBJ_SPHERE) {
+    const DevSphere& s = sc.spheres[ob.first];
+    const V3 lo = xf_pt(s.w2l, o), ld = normalize(xf_vec(s.w2l, d));
+    const V3 pl = lo + ld * best_t;
+    hit.p = xf_pt(s.l2w, pl);                        // src/shapes/sphere.rs:98
+    hit.n = normalize(xf_vec_t(s.w2l, pl));          // src/shapes/sphere.rs:37-43
+  } else {
+    const double* v = ob.kind == RT_OBJ_TRIANGLE ? sc.top_tris[ob.first].v : sc.mesh_tris[ob.first + best_slot].v;
+    const V3 v0 = ld3(v), v1 = ld3(v + 3), v2 = ld3(v + 6);
+    hit.p = o + dn * best_raw;                                       // src/shapes/triangle.rs:78-81
+    hit.n = normalize(normalize(cross(v1 - v0, v2 - v0)));          // src/shapes/triangle.rs:30, then :91
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------------- spectra
+
+// Per-hit spectrum rows, one byte per hit, kept in two uint4 registers.
+struct Chain { uint4 a, b; };
+
+__device__ __forceinline__ uint32_t& chain_word(Chain& c, int w) {
+  switch (w) {
+    case 0: return c.a.x; case 1: return c.a.y; case 2: return c.a.z; case 3: return c.a.w;
+    case 4: return c.b.x; case 5: return c.b.y; case 6: return c.b.z; default: return c.b.w;
+  }
+}
+__device__ __forceinline__ void chain_set(Chain& c, uint32_t k, uint32_t row) {
+#pragma unroll
+  for (int w = 0; w < 8; ++w)
+    if (int(k >> 2) == w) chain_word(c, w) = (chain_word(c, w) & ~(0xFFu << ((k & 3u) * 8u))) | (row << ((k & 3u) * 8u));
+}
+__device__ __forceinline__ uint32_t chain_get(const Chain& c, uint32_t k) {
+  uint32_t word = 0;
+  Chain& m = const_cast<Chain&>(c);
+#pragma unroll
+  for (int w = 0; w < 8; ++w)
+    if (int(k >> 2) == w) word = chain_word(m, w);
+  return (word >> ((k & 3u) * 8u)) & 0xFFu;
+}
+
+// The sample's spectrum when a path ends on an emitter: ((Le * c_k) * c_{k-1}) ... * c_1, the
+// innermost-first order of the reference's recursion (src/scene.rs:75,111), then to_XYZ
+// (src/spectrum/mod.rs:590-609). Exact binary32 products and sums, no contraction.
+__device__ __forceinline__ void emit_sample(const float* __restrict__ spectra, uint32_t emitted_row, const Chain& chain,
+                                            uint32_t n_chain, float xyz[3], float* spectrum_out) {
+  float x = 0.0f, y = 0.0f, z = 0.0f;
+  const float4* table = reinterpret_cast<const float4*>(spectra);
+  for (int q = 0; q < RT_NBINS / 4; ++q) {
+    float4 v = table[emitted_row * (RT_NBINS / 4) + q];
+    for (int k = int(n_chain) - 1; k >= 0; --k) {
+      const uint32_t row = chain_get(chain, uint32_t(k));
+      if (row != RT_NO_SPECTRUM) {
+        const float4 c = table[row * (RT_NBINS / 4) + q];
+        v.x = (v.x * c.x); v.y = (v.y * c.y); v.z = (v.z * c.z); v.w = (v.w * c.w);
+      }
+    }
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = q * 4 + j;
+      x = (x + (c_cie[0][i] * e[j]));
+      y = (y + (c_cie[1][i] * e[j]));
+      z = (z + (c_cie[2][i] * e[j]));
+      if (spectrum_out) spectrum_out[i] = e[j];
+    }
+  }
+  xyz[0] = (x * c_xyz_scale); xyz[1] = (y * c_xyz_scale); xyz[2] = (z * c_xyz_scale);
+}
+
+// NormalIntegrator: from_RGB(n * 0.5 + 0.5, Reflectance) then to_XYZ
+// (src/integrators/normal.rs:48-59, src/spectrum/mod.rs:525-581).
+__device__ __forceinline__ void normal_sample(V3 n, float xyz[3], float* spectrum_out) {
+  const float r = float(fma(n.x, 0.5, 0.5)), g = float(fma(n.y, 0.5, 0.5)), b = float(fma(n.z, 0.5, 0.5));
+  enum { W, C, M, Y, R, G, B };
+  int s1, s2; float k0, k1, k2;
+  if (r < g && r < b) {
+    k0 = r;
+    if (g < b) { s1 = C; k1 = g - r; s2 = B; k2 = b - g; } else { s1 = C; k1 = b - r; s2 = G; k2 = g - b; }
+  } else if (g < r && g < b) {
+    k0 = g;
+    if (r < b) { s1 = M; k1 = r - g; s2 = B; k2 = b - r; } else { s1 = M; k1 = b - g; s2 = R; k2 = r - b; }
+  } else {
+    k0 = b;
+    if (r < g) { s1 = Y; k1 = r - b; s2 = G; k2 = g - r; } else { s1 = Y; k1 = g - b; s2 = R; k2 = r - g; }
+  }
+  float x = 0.0f, y = 0.0f, z = 0.0f;
+  for (int i = 0; i < RT_NBINS; ++i) {
+    float v = (0.0f + (c_smits_refl[W][i] * k0));
+    v = (v + (c_smits_refl[s1][i] * k1));
+    v = (v + (c_smits_refl[s2][i] * k2));
+    x = (x + (c_cie[0][i] * v));
+    y = (y + (c_cie[1][i] * v));
+    z = (z + (c_cie[2][i] * v));
+    if (spectrum_out) spectrum_out[i] = v;
+  }
+  xyz[0] = (x * c_xyz_scale); xyz[1] = (y * c_xyz_scale); xyz[2] = (z * c_xyz_scale);
+}
+
+// ------------------------------------------------------------------------------- sampling
+
+// Cosine-weighted direction about n (src/geometry/mod.rs:85-116): r1 first, then r2.
+__device__ __forceinline__ V3 cosine_direction(V3 n, double r1, double r2) {
+  const double sin_t = sqrt(r1);
+  const double cos_t = sqrt(1.0 - sin_t * sin_t);
+  const double phi = 2.0 * M_PI * r2;
+  double sp, cp;
+  sincos(phi, &sp, &cp);
+  const V3 v = mk(cp * sin_t, sp * sin_t, cos_t);
+  V3 b1 = fabs(n.x) > 0.9 ? mk(0.0, 1.0, 0.0) : mk(1.0, 0.0, 0.0);
+  b1 = b1 - n * dot(b1, n);
+  b1 = b1 * (1.0 / sqrt(dot(b1, b1)));
+  const V3 b2 = cross(n, b1);
+  return mk((b1.x * v.x + b2.x * v.y) + n.x * v.z, (b1.y * v.x + b2.y * v.y) + n.y * v.z,
+            (b1.z * v.x + b2.z * v.y) + n.z * v.z);
+}
+
+// ------------------------------------------------------------------------------- queues
+
+__device__ __forceinline__ void queue_store(const PathQueue& q, uint32_t at, V3 o, V3 d, uint32_t pixel, uint32_t sample,
+                                            uint32_t slot, uint32_t remaining, const Chain& chain, bool deep) {
+  q.ox[at] = o.x; q.oy[at] = o.y; q.oz[at] = o.z;
+  q.dx[at] = d.x; q.dy[at] = d.y; q.dz[at] = d.z;
+  q.pixel[at] = pixel; q.sample[at] = sample; q.slot[at] = slot; q.remaining[at] = remaining;
+  q.chain0[at] = chain.a;
+  if (deep) q.chain1[at] = chain.b;
+}
+
+// local pixel of a batch -> image coordinates. Tiles are numbered x-major as the reference
+// enumerates them (src/integrators/integrator.rs:50); inside a tile, 64 consecutive local
+// pixels are one 8x8 block, so the primary rays of a wave stay together.
+__device__ __forceinline__ bool local_pixel_to_xy(const BatchDesc& b, uint32_t lp, uint32_t& x, uint32_t& y) {
+  const uint32_t per_tile = b.tile_size * b.tile_size;
+  const uint32_t tile = b.tile_list[lp / per_tile];
+  const uint32_t within = lp % per_tile;
+  const uint32_t blocks_per_row = b.tile_size / kPixelBlock;
+  const uint32_t block = within / (kPixelBlock * kPixelBlock), in_block = within % (kPixelBlock * kPixelBlock);
+  x = (tile / b.tiles_y) * b.tile_size + (block % blocks_per_row) * kPixelBlock + (in_block % kPixelBlock);
+  y = (tile % b.tiles_y) * b.tile_size + (block / blocks_per_row) * kPixelBlock + (in_block / kPixelBlock);
+  return x < b.cam.width && y < b.cam.height;
+}
+
+// ------------------------------------------------------------------------------- the bounce kernel
+
+// One bounce for every path of a queue. PRIMARY: the path starts here (camera ray from the
+// Philox jitter, or a caller ray); otherwise its state comes from `in`.
+//   miss / black material / depth exhausted : the path ends, contributing nothing
+//   emitter                                 : the path ends, contributing Le * (chain product)
+//   Lambertian / specular                   : the path continues into `out`
+template <bool PRIMARY, int RULE, bool COUNT>
+__global__ void __launch_bounds__(kBlock)
+bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_count, uint32_t max_in,
+              PathQueue out, uint32_t* __restrict__ out_count, TraceOutputs o, TraversalCounters* counters) {
+  extern __shared__ uint32_t lds_stack[];
+  uint32_t* stack = lds_stack + threadIdx.x;
+  const bool deep = b.max_depth > 16;
+  uint32_t n;
+  if (PRIMARY) n = b.rays ? b.n_rays : b.n_local_pixels * b.n_samples;
+  else { n = *in_count; n = n < max_in ? n : max_in; }
+  uint32_t n_nodes = 0, n_prims = 0;
+
+  for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+    const uint32_t idx = base + threadIdx.x;
+    bool active = idx < n;
+    V3 ro = mk(0, 0, 0), rd = mk(1, 0, 0);
+    uint32_t pixel = 0, sample = 0, slot = 0, remaining = 0;
+    Chain chain;
+    chain.a = make_uint4(0, 0, 0, 0); chain.b = make_uint4(0, 0, 0, 0);
+
+    if (active) {
+      if (PRIMARY) {
+        slot = idx;
+        remaining = b.integrator == RT_INT_RANDOM_WALK ? b.max_depth : 0;
+        if (b.rays) {
+          ro = ld3(b.rays + size_t(idx) * 6); rd = ld3(b.rays + size_t(idx) * 6 + 3);
+          pixel = b.pixel_base + idx; sample = b.sample0;
+        } else {
+          const uint32_t lp = idx % b.n_local_pixels;
+          sample = b.sample0 + idx / b.n_local_pixels;
+          uint32_t x, y;
+          active = local_pixel_to_xy(b, lp, x, y);
+          if (active) {
+            pixel = y * b.cam.width + x;
+            // evaluate_pixel_sample (src/integrators/integrator.rs:130-135) + Camera::get_ray (src/camera.rs:80-84)
+            double u0, u1;
+            uniform_pair(b.seed, pixel, sample, 0, 0, u0, u1);
+            const double fi = double(x) + u0 - 0.5, fj = double(y) + u1 - 0.5;
+            const V3 p1 = ld3(b.cam.p1), p2 = ld3(b.cam.p2), p3 = ld3(b.cam.p3), f = ld3(b.cam.focus);
+            const V3 right = ((p2 - p1) * fi) / double(b.cam.width);
+            const V3 down = ((p3 - p1) * fj) / double(b.cam.height);
+            ro = f;
+            rd = normalize(((p1 + right) + down) - f);
+          }
+        }
+      } else {
+        ro = mk(in.ox[idx], in.oy[idx], in.oz[idx]);
+        rd = mk(in.dx[idx], in.dy[idx], in.dz[idx]);
+        pixel = in.pixel[idx]; sample = in.sample[idx]; slot = in.slot[idx]; remaining = in.remaining[idx];
+        chain.a = in.chain0[idx];
+        if (deep) chain.b = in.chain1[idx];
+      }
+    }
+
+    bool alive = false;      // continues to the next bounce
+    V3 no = ro, nd = rd;
+    if (active) {
+      Hit hit;
+      const bool found = closest_hit<RULE, COUNT>(sc, ro, rd, stack, hit, n_nodes, n_prims);
+      float xyz[3];
+      bool contributes = false;
+      float* spectrum_out = o.spectra ? o.spectra + size_t(slot) * RT_NBINS : nullptr;
+      if (found) {
+        const DevMaterial m = sc.materials[sc.objects[hit.obj].material];
+        if (b.integrator == RT_INT_ALBEDO) {
+          // first present of ambient / emitted / diffused / specular (src/integrators/albedo.rs:54-68)
+          uint32_t row = RT_NO_SPECTRUM;
+          if (m.present & RT_HAS_AMBIENT) row = m.ambient;
+          else if (m.present & RT_HAS_EMITTED) row = m.emitted;
+          else if (m.present & RT_HAS_DIFFUSED) row = m.diffused;
+          else if (m.present & RT_HAS_SPECULAR) row = m.specular;
+          if (row != RT_NO_SPECTRUM) { emit_sample(sc.spectra, row, chain, 0, xyz, spectrum_out); contributes = true; }
+        } else if (b.integrator == RT_INT_NORMAL) {
+          normal_sample(hit.n, xyz, spectrum_out);   // un-turned geometric normal (src/integrators/normal.rs:50)
+          contributes = true;
+        } else if (remaining != 0) {                 // depth == 0 returns black after intersecting (random_walk.rs:68-70)
+          // a primary hit keeps its normal as is (random_walk.rs:74); later hits turn it against the ray (scene.rs:30-32)
+          if (!PRIMARY && dot(hit.n, rd) > 0.0) hit.n = neg(hit.n);
+          const uint32_t hit_index = b.max_depth - remaining;
+          if (m.type == RT_MAT_EMITTER) {            // src/scene.rs:56-62
+            if (m.present & RT_HAS_EMITTED) { emit_sample(sc.spectra, m.emitted, chain, hit_index, xyz, spectrum_out); contributes = true; }
+          } else if (m.type == RT_MAT_LAMBERTIAN) {  // src/scene.rs:63-79
+            if ((m.present & RT_HAS_AMBIENT) && remaining > 1) {
+              double r1, r2;
+              uniform_pair(b.seed, pixel, sample, hit_index, 1, r1, r2);
+              nd = normalize(cosine_direction(hit.n, r1, r2));
+              no = hit.p + hit.n * 1e-10;
+              chain_set(chain, hit_index, m.ambient);
+              alive = true;
+            }
+          } else if (remaining > 1) {                // Specular, src/scene.rs:80-112
+            nd = normalize(rd - hit.n * (2.0 * dot(rd, hit.n)));
+            no = hit.p + hit.n * 1e-10;
+            chain_set(chain, hit_index, (m.present & RT_HAS_SPECULAR) ? uint32_t(m.specular) : uint32_t(RT_NO_SPECTRUM));
+            alive = true;
+          }
+        }
+      }
+      if (contributes) {
+        o.contrib_x[slot] = xyz[0]; o.contrib_y[slot] = xyz[1]; o.contrib_z[slot] = xyz[2];
+      } else if (spectrum_out && !alive) {
+        for (int i = 0; i < RT_NBINS; ++i) spectrum_out[i] = 0.0f;
+      }
+    }
+
+    // wave-level compaction: one ballot, one atomic per wave, survivors packed in lane order
+    const unsigned long long mask = __ballot(alive);
+    if (mask) {
+      const uint32_t lane = __lane_id();
+      const uint32_t leader = uint32_t(__ffsll((long long)mask)) - 1u;
+      uint32_t start = 0;
+      if (lane == leader) start = atomicAdd(out_count, uint32_t(__popcll(mask)));
+      start = __shfl(start, int(leader));
+      if (alive) {
+        const uint32_t at = start + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+        queue_store(out, at, no, nd, pixel, sample, slot, remaining - 1, chain, deep);
+      }
+    }
+  }
+
+  if (COUNT) {
+    unsigned long long a = n_nodes, c = n_prims;
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); c += __shfl_down(c, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&counters->nodes, a); atomicAdd(&counters->prims, c); }
+  }
+}
+
+// Scene::intersect_ray over a batch of caller rays; writes rtmi_hit records.
+struct HitOut { uint32_t obj, prim; double t; double p[3]; double n[3]; };
+static_assert(sizeof(HitOut) == 64, "hit record must be 64 bytes");
+
+template <int RULE, bool COUNT>
+__global__ void __launch_bounds__(kBlock)
+intersect_kernel(DevScene sc, const double* __restrict__ rays, size_t n, HitOut* __restrict__ hits, TraversalCounters* counters) {
+  extern __shared__ uint32_t lds_stack[];
+  uint32_t* stack = lds_stack + threadIdx.x;
+  uint32_t n_nodes = 0, n_prims = 0;
+  for (size_t idx = size_t(blockIdx.x) * kBlock + threadIdx.x; idx < n; idx += size_t(gridDim.x) * kBlock) {
+    const V3 o = ld3(rays + idx * 6), d = ld3(rays + idx * 6 + 3);
+    Hit hit;
+    HitOut h;
+    if (closest_hit<RULE, COUNT>(sc, o, d, stack, hit, n_nodes, n_prims)) {
+      h.obj = hit.obj; h.prim = hit.prim; h.t = hit.t;
+      h.p[0] = hit.p.x; h.p[1] = hit.p.y; h.p[2] = hit.p.z;
+      h.n[0] = hit.n.x; h.n[1] = hit.n.y; h.n[2] = hit.n.z;
+    } else {
+      h.obj = RT_MISS; h.prim = RT_MISS; h.t = 0.0;
+      h.p[0] = h.p[1] = h.p[2] = 0.0; h.n[0] = h.n[1] = h.n[2] = 0.0;
+    }
+    hits[idx] = h;
+  }
+  if (COUNT) {
+    unsigned long long a = n_nodes, c = n_prims;
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); c += __shfl_down(c, off); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&counters->nodes, a); atomicAdd(&counters->prims, c); }
+  }
+}
+
+// Per pixel of the batch: sum the samples' XYZ in sample order onto the running per-pixel sum.
+__global__ void __launch_bounds__(kBlock) resolve_kernel(BatchDesc b, TraceOutputs o, float* __restrict__ xyz_sum) {
+  const uint32_t lp = blockIdx.x * kBlock + threadIdx.x;
+  if (lp >= b.n_local_pixels) return;
+  uint32_t x, y;
+  if (!local_pixel_to_xy(b, lp, x, y)) return;
+  const size_t pix = size_t(y) * b.cam.width + x;
+  float sx = xyz_sum[pix * 3], sy = xyz_sum[pix * 3 + 1], sz = xyz_sum[pix * 3 + 2];
+  for (uint32_t s = 0; s < b.n_samples; ++s) {
+    const size_t slot = size_t(s) * b.n_local_pixels + lp;
+    sx += o.contrib_x[slot]; sy += o.contrib_y[slot]; sz += o.contrib_z[slot];
+  }
+  xyz_sum[pix * 3] = sx; xyz_sum[pix * 3 + 1] = sy; xyz_sum[pix * 3 + 2] = sz;
+}
+
+__global__ void sum_counts_kernel(const uint32_t* counts, uint32_t n, unsigned long long* total) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    unsigned long long s = 0;
+    for (uint32_t i = 0; i < n; ++i) s += counts[i];
+    *total += s;
+  }
+}
+
+// mean, XYZ -> RGB, clamp, gamma 1/2.2, `(256 * v) as u8` (src/integrators/integrator.rs:79-90,
+// src/spectrum/mod.rs:630-636). A Rust float->u8 cast saturates and maps NaN to 0.
+__global__ void __launch_bounds__(kBlock) tonemap_kernel(const float* __restrict__ xyz_sum, float spp, uint32_t n_pixels,
+                                                         uint8_t* __restrict__ rgb8) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_pixels) return;
+  const float x = (xyz_sum[i * 3] / spp), y = (xyz_sum[i * 3 + 1] / spp), z = (xyz_sum[i * 3 + 2] / spp);
+  float rgb[3];
+  rgb[0] = 3.2404790f * x - 1.537150f * y - 0.498535f * z;
+  rgb[1] = -0.969256f * x + 1.875991f * y + 0.041556f * z;
+  rgb[2] = 0.0556480f * x - 0.204043f * y + 1.057311f * z;
+  for (int k = 0; k < 3; ++k) {
+    float c = rgb[k];
+    if (c < 0.0f) c = 0.0f;
+    if (c > 1.0f) c = 1.0f;
+    const float v = 256.0f * powf(c, 1.0f / 2.2f);
+    uint8_t q;
+    if (!(v == v) || v <= 0.0f) q = 0; else if (v >= 255.0f) q = 255; else q = uint8_t(v);
+    rgb8[i * 3 + k] = q;
+  }
+}
+
+inline uint32_t grid_for(size_t n) {
+  const size_t blocks = (n + kBlock - 1) / kBlock;
+  const size_t cap = 256 * 8;  // 256 CUs, up to 8 resident blocks each; longer queues are grid-strided
+  return uint32_t(blocks < 1 ? 1 : (blocks < cap ? blocks : cap));
+}
+
+inline size_t stack_bytes(const DevScene& sc) { return size_t(sc.stack_entries) * kBlock * sizeof(uint32_t); }
+
+}  // namespace
+
+#define RTMI_DISPATCH(KERNEL, PRIM, ...)                                                                       \
+  do {                                                                                                         \
+    const bool count_ = counters != nullptr;                                                                   \
+    if (sc.hit_rule == RT_HIT_FIRST_INDEX) {                                                                   \
+      if (count_) hipLaunchKernelGGL((KERNEL<PRIM, RT_HIT_FIRST_INDEX, true>), grid, kBlock, lds, s, __VA_ARGS__);  \
+      else hipLaunchKernelGGL((KERNEL<PRIM, RT_HIT_FIRST_INDEX, false>), grid, kBlock, lds, s, __VA_ARGS__);        \
+    } else {                                                                                                   \
+      if (count_) hipLaunchKernelGGL((KERNEL<PRIM, RT_HIT_NEAREST, true>), grid, kBlock, lds, s, __VA_ARGS__);      \
+      else hipLaunchKernelGGL((KERNEL<PRIM, RT_HIT_NEAREST, false>), grid, kBlock, lds, s, __VA_ARGS__);            \
+    }                                                                                                          \
+  } while (0)
+
+void launch_primary(const DevScene& sc, const BatchDesc& b, PathQueue out, uint32_t* out_count, TraceOutputs o,
+                    TraversalCounters* counters, hipStream_t s) {
+  const size_t n = b.rays ? size_t(b.n_rays) : size_t(b.n_local_pixels) * b.n_samples;
+  if (n == 0) return;
+  const dim3 grid(grid_for(n));
+  const size_t lds = stack_bytes(sc);
+  PathQueue none{};
+  RTMI_DISPATCH(bounce_kernel, true, sc, b, none, (const uint32_t*)nullptr, 0u, out, out_count, o, counters);
+}
+
+void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const uint32_t* in_count, uint32_t max_in,
+                   PathQueue out, uint32_t* out_count, TraceOutputs o, TraversalCounters* counters, hipStream_t s) {
+  if (max_in == 0) return;
+  const dim3 grid(grid_for(max_in));
+  const size_t lds = stack_bytes(sc);
+  RTMI_DISPATCH(bounce_kernel, false, sc, b, in, in_count, max_in, out, out_count, o, counters);
+}
+
+template <int RULE, bool COUNT>
+static void launch_intersect_t(const DevScene& sc, const void* rays, size_t n, void* hits, TraversalCounters* counters,
+                               hipStream_t s) {
+  hipLaunchKernelGGL((intersect_kernel<RULE, COUNT>), dim3(grid_for(n)), kBlock, stack_bytes(sc), s, sc,
+                     static_cast<const double*>(rays), n, static_cast<HitOut*>(hits), counters);
+}
+
+void launch_intersect(const DevScene& sc, const void* rays, size_t n, void* hits, TraversalCounters* counters, hipStream_t s) {
+  if (n == 0) return;
+  if (sc.hit_rule == RT_HIT_FIRST_INDEX) {
+    if (counters) launch_intersect_t<RT_HIT_FIRST_INDEX, true>(sc, rays, n, hits, counters, s);
+    else launch_intersect_t<RT_HIT_FIRST_INDEX, false>(sc, rays, n, hits, counters, s);
+  } else {
+    if (counters) launch_intersect_t<RT_HIT_NEAREST, true>(sc, rays, n, hits, counters, s);
+    else launch_intersect_t<RT_HIT_NEAREST, false>(sc, rays, n, hits, counters, s);
+  }
+}
+
+void launch_resolve(const BatchDesc& b, TraceOutputs o, float* xyz_sum, hipStream_t s) {
+  if (b.n_local_pixels == 0) return;
+  hipLaunchKernelGGL(resolve_kernel, dim3((b.n_local_pixels + kBlock - 1) / kBlock), kBlock, 0, s, b, o, xyz_sum);
+}
+
+void launch_sum_counts(const uint32_t* counts, uint32_t n, unsigned long long* total, hipStream_t s) {
+  hipLaunchKernelGGL(sum_counts_kernel, dim3(1), 64, 0, s, counts, n, total);
+}
+
+void launch_tonemap(const float* xyz_sum, uint32_t spp, uint32_t n_pixels, uint8_t* rgb8, hipStream_t s) {
+  if (n_pixels == 0) return;
+  hipLaunchKernelGGL(tonemap_kernel, dim3((n_pixels + kBlock - 1) / kBlock), kBlock, 0, s, xyz_sum, float(spp), n_pixels, rgb8);
+}
+
+}  // namespace rtmi

@@ -1,0 +1,92 @@
+// rt_types.h -- plain-data layouts shared by the host scene builder and the HIP kernels.
+//
+// Everything here is what actually sits in HBM:
+//   objects   : the scene's object list in scene order (the closest-hit loop walks it like
+//               Scene::intersect_ray does, src/scene.rs:135-150)
+//   spheres   : local->world and world->local maps + radius (the inverse the reference recomputes
+//               per test, src/shapes/sphere.rs:39,52, is stored once)
+//   top_tris  : lone triangles with their flat normal
+//   nodes     : one binary BVH per mesh, 64-byte nodes, all meshes concatenated
+//   mesh_tris : mesh triangles in BVH leaf order, f64 vertices + their file-order index
+//   materials : type tag + indices into a table of 60-bin spectra
+#pragma once
+#include <stdint.h>
+
+#define RT_NBINS 60
+#define RT_MISS 0xFFFFFFFFu
+#define RT_MAX_DEPTH 32
+#define RT_LEAF_FLAG 0x80000000u
+#define RT_REF_NONE 0xFFFFFFFFu     // empty child slot
+#define RT_LEAF_MAX_TRIS 15
+#define RT_NO_SPECTRUM 0xFFu        // chain entry meaning "multiply by 1.0" / absent spectrum
+
+enum { RT_OBJ_SPHERE = 0, RT_OBJ_TRIANGLE = 1, RT_OBJ_MODEL = 2 };
+enum { RT_MAT_EMITTER = 0, RT_MAT_LAMBERTIAN = 1, RT_MAT_SPECULAR = 2 };
+enum { RT_HAS_AMBIENT = 1, RT_HAS_EMITTED = 2, RT_HAS_DIFFUSED = 4, RT_HAS_SPECULAR = 8 };
+enum { RT_HIT_FIRST_INDEX = 0, RT_HIT_NEAREST = 1 };
+enum { RT_INT_RANDOM_WALK = 0, RT_INT_ALBEDO = 1, RT_INT_NORMAL = 2 };
+
+struct DevObject {
+  uint32_t kind;
+  uint32_t first;      // sphere index / top_tris index / first mesh triangle (leaf order base)
+  uint32_t count;
+  uint32_t material;
+  uint32_t root;       // models: index of the BVH root node
+  uint32_t pad[3];
+};
+
+struct DevSphere {
+  double l2w[12];
+  double w2l[12];
+  double radius;
+  double pad;
+};
+
+struct DevTopTri {
+  double v[9];
+  double n[3];         // normalize((p2-p1) x (p3-p1)), src/shapes/triangle.rs:30
+};
+
+// Child reference: RT_LEAF_FLAG | first << 4 | count for a leaf (first is relative to the
+// model's first mesh triangle), a node index (relative to the model's root) otherwise,
+// RT_REF_NONE for an empty slot. min_index = smallest file-order triangle index below the child.
+struct BvhNode {
+  float lo0[3], hi0[3];
+  float lo1[3], hi1[3];
+  uint32_t ref0, ref1;
+  uint32_t min_index0, min_index1;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+struct DevMeshTri {
+  double v[9];
+  uint32_t index;      // file-order index inside its model
+  uint32_t pad;
+};
+static_assert(sizeof(DevMeshTri) == 80, "DevMeshTri must be 80 bytes");
+
+struct DevMaterial {
+  uint32_t type;
+  uint32_t present;
+  uint8_t ambient, emitted, diffused, specular;  // rows of the spectrum table, RT_NO_SPECTRUM if absent
+  uint32_t pad;
+};
+
+struct DevScene {
+  const DevObject* objects;
+  const DevSphere* spheres;
+  const DevTopTri* top_tris;
+  const BvhNode* nodes;
+  const DevMeshTri* mesh_tris;
+  const DevMaterial* materials;
+  const float* spectra;       // n_spectra x 60
+  uint32_t n_objects;
+  uint32_t hit_rule;
+  uint32_t stack_entries;     // LDS traversal stack depth per lane
+  uint32_t n_spectra;
+};
+
+struct DevCamera {
+  double focus[3], p1[3], p2[3], p3[3];
+  uint32_t width, height;
+};

@@ -1,0 +1,654 @@
+// rtmi_api.cpp -- host runtime behind the C ABI in include/rtmi.h: argument checking, scene
+// flattening and upload, batch scheduling of the per-bounce kernels, statistics.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/rtmi.h"
+#include "bvh.h"
+#include "rt_kernels.h"
+#include "rt_types.h"
+#include "spectrum.h"
+
+using namespace rtmi;
+
+// the public structs and the device-side ones describe the same bytes
+static_assert(RTMI_NBINS == RT_NBINS && RTMI_MAX_DEPTH == RT_MAX_DEPTH, "constants out of sync");
+static_assert(sizeof(rtmi_hit) == 64 && sizeof(rtmi_ray) == 48, "ABI layout");
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(e_ == hipErrorOutOfMemory ? RTMI_OOM : RTMI_HIP_ERROR, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// Grow-only device buffer.
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return RTMI_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    HIP_TRY(hipMalloc(&p, bytes));
+    cap = bytes;
+    return RTMI_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct DeviceStats { unsigned long long bounce_segments; TraversalCounters trav; };
+
+}  // namespace
+
+struct rtmi_ctx {
+  int device = 0;
+  uint64_t max_batch_paths = 0;
+  // workspace shared by every scene of the context (one call at a time per context)
+  DevBuf queue_mem[2];
+  PathQueue queue[2];
+  size_t queue_paths = 0;
+  bool queue_deep = false;
+  DevBuf contrib, counts, tiles, stats, rays, hits, spectra_out, image;
+};
+
+struct rtmi_scene {
+  rtmi_ctx* ctx = nullptr;
+  DevScene dev{};
+  DevBuf objects, spheres, top_tris, nodes, mesh_tris, materials, spectra;
+  rtmi_scene_info info{};
+  // bookkeeping of the last render_accumulate, completed by rtmi_render_collect_stats
+  rtmi_stats pending{};
+  bool counting = false;
+};
+
+namespace {
+
+constexpr uint64_t kDefaultBatchPaths = 1ull << 24;  // 16 Mi path slots, about 3.5 GB of workspace
+
+int bind(const rtmi_ctx* ctx) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  return RTMI_OK;
+}
+
+PathQueue carve_queue(void* base, size_t paths, bool deep) {
+  PathQueue q;
+  char* p = static_cast<char*>(base);
+  auto take = [&](size_t bytes) { void* r = p; p += (bytes + 255) & ~size_t(255); return r; };
+  q.ox = (double*)take(paths * 8); q.oy = (double*)take(paths * 8); q.oz = (double*)take(paths * 8);
+  q.dx = (double*)take(paths * 8); q.dy = (double*)take(paths * 8); q.dz = (double*)take(paths * 8);
+  q.pixel = (uint32_t*)take(paths * 4); q.sample = (uint32_t*)take(paths * 4);
+  q.slot = (uint32_t*)take(paths * 4); q.remaining = (uint32_t*)take(paths * 4);
+  q.chain0 = (uint4*)take(paths * 16);
+  q.chain1 = deep ? (uint4*)take(paths * 16) : nullptr;
+  return q;
+}
+
+size_t queue_bytes(size_t paths, bool deep) { return paths * (6 * 8 + 4 * 4 + 16 + (deep ? 16 : 0)) + 12 * 256; }
+
+int ensure_workspace(rtmi_ctx* ctx, size_t paths, bool deep, bool want_queues) {
+  if (want_queues && (paths > ctx->queue_paths || (deep && !ctx->queue_deep))) {
+    const size_t p = std::max(paths, ctx->queue_paths);
+    const bool d = deep || ctx->queue_deep;
+    for (int i = 0; i < 2; ++i) {
+      ctx->queue_mem[i].release();
+      if (int rc = ctx->queue_mem[i].reserve(queue_bytes(p, d))) return rc;
+      ctx->queue[i] = carve_queue(ctx->queue_mem[i].p, p, d);
+    }
+    ctx->queue_paths = p; ctx->queue_deep = d;
+  }
+  if (int rc = ctx->contrib.reserve(paths * 3 * sizeof(float))) return rc;
+  if (int rc = ctx->counts.reserve((RT_MAX_DEPTH + 2) * sizeof(uint32_t))) return rc;
+  if (!ctx->stats.p) {
+    if (int rc = ctx->stats.reserve(sizeof(DeviceStats))) return rc;
+    HIP_TRY(hipMemset(ctx->stats.p, 0, sizeof(DeviceStats)));
+  }
+  return RTMI_OK;
+}
+
+bool affine_inverse(const double* m, double* out) {
+  const double a00 = m[0], a01 = m[1], a02 = m[2], a10 = m[4], a11 = m[5], a12 = m[6], a20 = m[8], a21 = m[9], a22 = m[10];
+  const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+  const double det = (a00 * c00 + a01 * c01) + a02 * c02;
+  if (det == 0.0 || !std::isfinite(det)) return false;
+  const double id = 1.0 / det;
+  out[0] = c00 * id; out[1] = (a02 * a21 - a01 * a22) * id; out[2] = (a01 * a12 - a02 * a11) * id;
+  out[4] = c01 * id; out[5] = (a00 * a22 - a02 * a20) * id; out[6] = (a02 * a10 - a00 * a12) * id;
+  out[8] = c02 * id; out[9] = (a01 * a20 - a00 * a21) * id; out[10] = (a00 * a11 - a01 * a10) * id;
+  for (int i = 0; i < 3; ++i) out[i * 4 + 3] = -((out[i * 4] * m[3] + out[i * 4 + 1] * m[7]) + out[i * 4 + 2] * m[11]);
+  return true;
+}
+
+template <class T>
+int upload(DevBuf& buf, const std::vector<T>& v) {
+  if (int rc = buf.reserve(std::max<size_t>(v.size() * sizeof(T), 256))) return rc;
+  if (!v.empty()) HIP_TRY(hipMemcpy(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return RTMI_OK;
+}
+
+struct Timer {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// HIP-event bracket around closest-hit launches (RTMI_FLAG_TIME_KERNELS)
+struct KernelClock {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+  bool on = false;
+  hipStream_t stream = nullptr;
+  void begin() {
+    if (!on) return;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, stream);
+    spans.emplace_back(a, b);
+  }
+  void end() { if (on) (void)hipEventRecord(spans.back().second, stream); }
+  double drain() {  // waits for the recorded work
+    double total = 0.0;
+    for (auto& s : spans) {
+      (void)hipEventSynchronize(s.second);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, s.first, s.second);
+      total += ms;
+      (void)hipEventDestroy(s.first); (void)hipEventDestroy(s.second);
+    }
+    spans.clear();
+    return total;
+  }
+};
+
+DevCamera to_dev_camera(const rtmi_camera& c) {
+  DevCamera d;
+  std::memcpy(d.focus, c.focus, sizeof d.focus); std::memcpy(d.p1, c.p1, sizeof d.p1);
+  std::memcpy(d.p2, c.p2, sizeof d.p2); std::memcpy(d.p3, c.p3, sizeof d.p3);
+  d.width = c.width; d.height = c.height;
+  return d;
+}
+
+// Runs primary + bounce launches for one batch and leaves per-slot contributions in ctx->contrib.
+int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra_out, hipStream_t stream,
+              KernelClock& clock, uint32_t& launches) {
+  rtmi_ctx* ctx = sc->ctx;
+  uint32_t* counts = ctx->counts.as<uint32_t>();
+  float* contrib = ctx->contrib.as<float>();
+  TraceOutputs o{contrib, contrib + n_paths, contrib + 2 * n_paths, spectra_out};
+  DeviceStats* ds = ctx->stats.as<DeviceStats>();
+  TraversalCounters* counters = sc->counting ? &ds->trav : nullptr;
+  HIP_TRY(hipMemsetAsync(counts, 0, (RT_MAX_DEPTH + 2) * sizeof(uint32_t), stream));
+  HIP_TRY(hipMemsetAsync(contrib, 0, n_paths * 3 * sizeof(float), stream));
+  clock.begin();
+  launch_primary(sc->dev, b, ctx->queue[0], counts + 1, o, counters, stream);
+  clock.end();
+  ++launches;
+  const uint32_t depth = b.integrator == RT_INT_RANDOM_WALK ? b.max_depth : 0;
+  for (uint32_t k = 1; k < depth; ++k) {
+    clock.begin();
+    launch_bounce(sc->dev, b, ctx->queue[(k - 1) & 1], counts + k, uint32_t(n_paths), ctx->queue[k & 1], counts + k + 1, o,
+                  counters, stream);
+    clock.end();
+    ++launches;
+  }
+  if (depth > 1) launch_sum_counts(counts + 1, depth - 1, &ds->bounce_segments, stream);
+  HIP_TRY(hipGetLastError());
+  return RTMI_OK;
+}
+
+int check_scene(const rtmi_scene* s) {
+  if (!s || !s->ctx) return fail(RTMI_BAD_ARG, "scene is NULL");
+  return bind(s->ctx);
+}
+
+}  // namespace
+
+// ================================================================================ context
+
+extern "C" const char* rtmi_last_error(void) { return g_error.c_str(); }
+extern "C" const char* rtmi_version(void) { return "rtmi 0.1.0 gfx950"; }
+
+extern "C" int rtmi_ctx_create(int device_id, uint64_t max_batch_paths, rtmi_ctx** out) {
+  if (!out) return fail(RTMI_BAD_ARG, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+    return fail(RTMI_NO_DEVICE, "no HIP device is visible; this library has no CPU path");
+  int dev = device_id;
+  if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+  if (dev >= n) return fail(RTMI_NO_DEVICE, "device %d requested, %d visible", dev, n);
+  HIP_TRY(hipSetDevice(dev));
+  std::unique_ptr<rtmi_ctx> ctx(new rtmi_ctx);
+  ctx->device = dev;
+  ctx->max_batch_paths = max_batch_paths ? max_batch_paths : kDefaultBatchPaths;
+  if (ctx->max_batch_paths < 256) ctx->max_batch_paths = 256;
+  if (ctx->max_batch_paths > (1ull << 30)) ctx->max_batch_paths = 1ull << 30;
+  upload_constants(spectrum_tables());
+  HIP_TRY(hipGetLastError());
+  *out = ctx.release();
+  return RTMI_OK;
+}
+
+extern "C" void rtmi_ctx_destroy(rtmi_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (auto& q : ctx->queue_mem) q.release();
+  for (DevBuf* b : {&ctx->contrib, &ctx->counts, &ctx->tiles, &ctx->stats, &ctx->rays, &ctx->hits, &ctx->spectra_out, &ctx->image})
+    b->release();
+  delete ctx;
+}
+
+// ================================================================================ spectra, camera
+
+extern "C" int rtmi_spectrum_from_rgb(float r, float g, float b, int type, float out[RTMI_NBINS]) {
+  if (!out) return fail(RTMI_BAD_ARG, "out is NULL");
+  if (type != RTMI_SPEC_REFLECTANCE && type != RTMI_SPEC_ILLUMINANT) return fail(RTMI_BAD_ARG, "unknown spectrum type %d", type);
+  spectrum_from_rgb(r, g, b, type, out);
+  return RTMI_OK;
+}
+
+extern "C" int rtmi_spectrum_to_xyz(const float spectrum[RTMI_NBINS], float xyz[3]) {
+  if (!spectrum || !xyz) return fail(RTMI_BAD_ARG, "NULL argument");
+  spectrum_to_xyz(spectrum, xyz);
+  return RTMI_OK;
+}
+
+extern "C" int rtmi_xyz_to_rgb(const float xyz[3], float rgb[3]) {
+  if (!xyz || !rgb) return fail(RTMI_BAD_ARG, "NULL argument");
+  xyz_to_rgb(xyz, rgb);
+  return RTMI_OK;
+}
+
+extern "C" int rtmi_spectrum_cie_tables(float x[RTMI_NBINS], float y[RTMI_NBINS], float z[RTMI_NBINS]) {
+  if (!x || !y || !z) return fail(RTMI_BAD_ARG, "NULL argument");
+  const SpectrumTables& t = spectrum_tables();
+  std::memcpy(x, t.cie[0], sizeof t.cie[0]); std::memcpy(y, t.cie[1], sizeof t.cie[1]); std::memcpy(z, t.cie[2], sizeof t.cie[2]);
+  return RTMI_OK;
+}
+
+// Camera::new (src/camera.rs:19-51): screen corners from focal distance, horizontal field of
+// view in degrees and Rz(yaw) * Ry(pitch) * Rx(roll); the camera looks along local +X.
+extern "C" int rtmi_camera_new(const double focus[3], double focal_distance, double field_of_view_deg,
+                               const double rotation_rpy[3], uint32_t width, uint32_t height, rtmi_camera* out) {
+  if (!focus || !rotation_rpy || !out) return fail(RTMI_BAD_ARG, "NULL argument");
+  if (width == 0 || height == 0) return fail(RTMI_BAD_ARG, "camera resolution %ux%u", width, height);
+  const double dy = focal_distance * std::tan(field_of_view_deg / 2.0 * M_PI / 180.0);
+  const double dz = dy * double(height) / double(width);
+  const double sr = std::sin(rotation_rpy[0]), cr = std::cos(rotation_rpy[0]);
+  const double sp = std::sin(rotation_rpy[1]), cp = std::cos(rotation_rpy[1]);
+  const double sy = std::sin(rotation_rpy[2]), cy = std::cos(rotation_rpy[2]);
+  const double rot[9] = {cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr,
+                         sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr,
+                         -sp,     cp * sr,                cp * cr};
+  auto corner = [&](double y, double z, double* dst) {
+    const double v[3] = {focal_distance, y, z};
+    for (int i = 0; i < 3; ++i) dst[i] = ((rot[i * 3] * v[0] + rot[i * 3 + 1] * v[1]) + rot[i * 3 + 2] * v[2]) + focus[i];
+  };
+  corner(-dy, dz, out->p1); corner(dy, dz, out->p2); corner(-dy, -dz, out->p3); corner(dy, -dz, out->p4);
+  std::memcpy(out->focus, focus, 3 * sizeof(double));
+  out->width = width; out->height = height;
+  return RTMI_OK;
+}
+
+extern "C" int rtmi_camera_get_ray(const rtmi_camera* c, double i, double j, rtmi_ray* out) {
+  if (!c || !out) return fail(RTMI_BAD_ARG, "NULL argument");
+  double d[3];
+  for (int k = 0; k < 3; ++k) {
+    const double right = (c->p2[k] - c->p1[k]) * i / double(c->width);
+    const double down = (c->p3[k] - c->p1[k]) * j / double(c->height);
+    d[k] = ((c->p1[k] + right) + down) - c->focus[k];
+  }
+  const double len = std::sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+  for (int k = 0; k < 3; ++k) { out->o[k] = c->focus[k]; out->d[k] = d[k] / len; }
+  return RTMI_OK;
+}
+
+// ================================================================================ scene
+
+extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_scene** out) {
+  if (!ctx || !d || !out) return fail(RTMI_BAD_ARG, "NULL argument");
+  *out = nullptr;
+  if (int rc = bind(ctx)) return rc;
+  if (d->hit_rule != RTMI_HIT_FIRST_INDEX && d->hit_rule != RTMI_HIT_NEAREST) return fail(RTMI_BAD_ARG, "unknown hit rule %u", d->hit_rule);
+  if ((d->n_objects && !d->objects) || (d->n_spheres && !d->spheres) || (d->n_triangles && !d->triangles) ||
+      (d->n_materials && !d->materials))
+    return fail(RTMI_BAD_ARG, "a non-empty array is NULL");
+
+  std::vector<DevMaterial> mats(d->n_materials);
+  std::vector<float> spectra;
+  auto add_row = [&](const float* s) { spectra.insert(spectra.end(), s, s + RT_NBINS); return uint32_t(spectra.size() / RT_NBINS - 1); };
+  for (uint32_t i = 0; i < d->n_materials; ++i) {
+    const rtmi_material& m = d->materials[i];
+    if (m.type > RTMI_MAT_SPECULAR) return fail(RTMI_UNSUPPORTED, "material %u has unknown type %u", i, m.type);
+    DevMaterial dm{};
+    dm.type = m.type; dm.present = m.present & 15u;
+    dm.ambient = dm.emitted = dm.diffused = dm.specular = RT_NO_SPECTRUM;
+    uint32_t rows[4] = {RT_NO_SPECTRUM, RT_NO_SPECTRUM, RT_NO_SPECTRUM, RT_NO_SPECTRUM};
+    if (m.present & RTMI_HAS_AMBIENT) rows[0] = add_row(m.ambient);
+    if (m.present & RTMI_HAS_EMITTED) rows[1] = add_row(m.emitted);
+    if (m.present & RTMI_HAS_DIFFUSED) rows[2] = add_row(m.diffused);
+    if (m.present & RTMI_HAS_SPECULAR) rows[3] = add_row(m.specular);
+    if (spectra.size() / RT_NBINS >= RT_NO_SPECTRUM)
+      return fail(RTMI_UNSUPPORTED, "more than %d distinct material spectra", int(RT_NO_SPECTRUM) - 1);
+    dm.ambient = uint8_t(rows[0]); dm.emitted = uint8_t(rows[1]); dm.diffused = uint8_t(rows[2]); dm.specular = uint8_t(rows[3]);
+    mats[i] = dm;
+  }
+
+  std::vector<DevObject> objects(d->n_objects);
+  std::vector<DevSphere> spheres;
+  std::vector<DevTopTri> top_tris;
+  std::vector<BvhNode> nodes;
+  std::vector<DevMeshTri> mesh_tris;
+  uint32_t max_depth = 0;
+  for (uint32_t i = 0; i < d->n_objects; ++i) {
+    const rtmi_object& o = d->objects[i];
+    if (o.material >= d->n_materials) return fail(RTMI_BAD_ARG, "object %u: material %u out of range", i, o.material);
+    DevObject dobj{};
+    dobj.kind = o.kind; dobj.material = o.material; dobj.count = o.count;
+    if (o.kind == RTMI_OBJ_SPHERE) {
+      if (o.first >= d->n_spheres) return fail(RTMI_BAD_ARG, "object %u: sphere %u out of range", i, o.first);
+      DevSphere s{};
+      std::memcpy(s.l2w, d->spheres[o.first].l2w, sizeof s.l2w);
+      s.radius = d->spheres[o.first].radius;
+      if (!affine_inverse(s.l2w, s.w2l)) return fail(RTMI_BAD_ARG, "object %u: sphere transform is singular", i);
+      dobj.first = uint32_t(spheres.size());
+      spheres.push_back(s);
+    } else if (o.kind == RTMI_OBJ_TRIANGLE) {
+      if (o.first >= d->n_triangles) return fail(RTMI_BAD_ARG, "object %u: triangle %u out of range", i, o.first);
+      DevTopTri t{};
+      std::memcpy(t.v, d->triangles[o.first].v, sizeof t.v);
+      const double* v = t.v;
+      const double e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+      const double c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+      const double len = std::sqrt((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]);
+      for (int k = 0; k < 3; ++k) t.n[k] = c[k] / len;
+      dobj.first = uint32_t(top_tris.size());
+      top_tris.push_back(t);
+    } else if (o.kind == RTMI_OBJ_MODEL) {
+      if (uint64_t(o.first) + o.count > d->n_triangles) return fail(RTMI_BAD_ARG, "object %u: triangles [%u,+%u) out of range", i, o.first, o.count);
+      if (o.count >= (1u << 27)) return fail(RTMI_UNSUPPORTED, "object %u: %u triangles in one mesh", i, o.count);
+      BvhBuild bb = build_bvh(o.count ? d->triangles[o.first].v : nullptr, o.count, 4);
+      dobj.root = uint32_t(nodes.size());
+      dobj.first = uint32_t(mesh_tris.size());
+      nodes.insert(nodes.end(), bb.nodes.begin(), bb.nodes.end());
+      mesh_tris.insert(mesh_tris.end(), bb.tris.begin(), bb.tris.end());
+      max_depth = std::max(max_depth, bb.max_depth);
+    } else {
+      return fail(RTMI_UNSUPPORTED, "object %u has unknown kind %u", i, o.kind);
+    }
+    objects[i] = dobj;
+  }
+  const uint32_t stack_entries = nodes.empty() ? 0 : max_depth + 1;
+  if (size_t(stack_entries) * kBlock * sizeof(uint32_t) > 160 * 1024)
+    return fail(RTMI_UNSUPPORTED, "BVH depth %u needs more LDS than a CU has", max_depth);
+
+  std::unique_ptr<rtmi_scene> s(new rtmi_scene);
+  s->ctx = ctx;
+  int rc;
+  if ((rc = upload(s->objects, objects)) || (rc = upload(s->spheres, spheres)) || (rc = upload(s->top_tris, top_tris)) ||
+      (rc = upload(s->nodes, nodes)) || (rc = upload(s->mesh_tris, mesh_tris)) || (rc = upload(s->materials, mats)) ||
+      (rc = upload(s->spectra, spectra))) {
+    rtmi_scene_destroy(s.release());
+    return rc;
+  }
+  s->dev.objects = s->objects.as<DevObject>(); s->dev.spheres = s->spheres.as<DevSphere>();
+  s->dev.top_tris = s->top_tris.as<DevTopTri>(); s->dev.nodes = s->nodes.as<BvhNode>();
+  s->dev.mesh_tris = s->mesh_tris.as<DevMeshTri>(); s->dev.materials = s->materials.as<DevMaterial>();
+  s->dev.spectra = s->spectra.as<float>();
+  s->dev.n_objects = d->n_objects; s->dev.hit_rule = d->hit_rule; s->dev.stack_entries = stack_entries;
+  s->dev.n_spectra = uint32_t(spectra.size() / RT_NBINS);
+  s->info.n_nodes = uint32_t(nodes.size()); s->info.max_depth = max_depth;
+  s->info.n_mesh_triangles = uint32_t(mesh_tris.size()); s->info.n_spectra = s->dev.n_spectra;
+  s->info.node_bytes = nodes.size() * sizeof(BvhNode); s->info.triangle_bytes = mesh_tris.size() * sizeof(DevMeshTri);
+  *out = s.release();
+  return RTMI_OK;
+}
+
+extern "C" void rtmi_scene_destroy(rtmi_scene* s) {
+  if (!s) return;
+  if (s->ctx) { (void)hipSetDevice(s->ctx->device); (void)hipDeviceSynchronize(); }
+  for (DevBuf* b : {&s->objects, &s->spheres, &s->top_tris, &s->nodes, &s->mesh_tris, &s->materials, &s->spectra}) b->release();
+  delete s;
+}
+
+extern "C" int rtmi_scene_get_info(const rtmi_scene* s, rtmi_scene_info* out) {
+  if (!s || !out) return fail(RTMI_BAD_ARG, "NULL argument");
+  *out = s->info;
+  return RTMI_OK;
+}
+
+// ================================================================================ intersect
+
+extern "C" int rtmi_intersect_batch_device(rtmi_scene* s, const rtmi_ray* dev_rays, size_t n, rtmi_hit* dev_hits, void* stream) {
+  if (int rc = check_scene(s)) return rc;
+  if (n && (!dev_rays || !dev_hits)) return fail(RTMI_BAD_ARG, "NULL ray or hit buffer");
+  launch_intersect(s->dev, dev_rays, n, dev_hits, nullptr, static_cast<hipStream_t>(stream));
+  HIP_TRY(hipGetLastError());
+  return RTMI_OK;
+}
+
+extern "C" int rtmi_intersect_batch(rtmi_scene* s, const rtmi_ray* rays, size_t n, rtmi_hit* hits, rtmi_stats* stats) {
+  if (int rc = check_scene(s)) return rc;
+  if (n && (!rays || !hits)) return fail(RTMI_BAD_ARG, "NULL ray or hit buffer");
+  rtmi_ctx* ctx = s->ctx;
+  Timer timer;
+  const size_t chunk = std::min<size_t>(std::max<size_t>(n, 1), size_t(1) << 24);
+  if (int rc = ctx->rays.reserve(chunk * sizeof(rtmi_ray))) return rc;
+  if (int rc = ctx->hits.reserve(chunk * sizeof(rtmi_hit))) return rc;
+  if (int rc = ensure_workspace(ctx, 1, false, false)) return rc;
+  DeviceStats* ds = ctx->stats.as<DeviceStats>();
+  const bool count = stats != nullptr;
+  if (count) HIP_TRY(hipMemset(ds, 0, sizeof *ds));
+  for (size_t at = 0; at < n; at += chunk) {
+    const size_t m = std::min(chunk, n - at);
+    HIP_TRY(hipMemcpy(ctx->rays.p, rays + at, m * sizeof(rtmi_ray), hipMemcpyHostToDevice));
+    launch_intersect(s->dev, ctx->rays.p, m, ctx->hits.p, count ? &ds->trav : nullptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(hits + at, ctx->hits.p, m * sizeof(rtmi_hit), hipMemcpyDeviceToHost));
+  }
+  if (stats) {
+    DeviceStats h;
+    HIP_TRY(hipMemcpy(&h, ds, sizeof h, hipMemcpyDeviceToHost));
+    std::memset(stats, 0, sizeof *stats);
+    stats->segments = n; stats->paths = n;
+    stats->nodes_visited = h.trav.nodes; stats->prims_tested = h.trav.prims;
+    stats->ms_total = timer.ms();
+  }
+  return RTMI_OK;
+}
+
+// ================================================================================ trace
+
+extern "C" int rtmi_trace_batch(rtmi_scene* s, const rtmi_ray* rays, size_t n, uint32_t integrator, uint32_t max_depth,
+                                uint64_t seed, uint32_t pixel_base, uint32_t sample_index, float* spectra, rtmi_stats* stats) {
+  if (int rc = check_scene(s)) return rc;
+  if (n && (!rays || !spectra)) return fail(RTMI_BAD_ARG, "NULL ray or output buffer");
+  if (integrator > RTMI_INT_NORMAL) return fail(RTMI_BAD_ARG, "unknown integrator %u", integrator);
+  if (max_depth > RTMI_MAX_DEPTH) return fail(RTMI_UNSUPPORTED, "max_depth %u > %d", max_depth, RTMI_MAX_DEPTH);
+  rtmi_ctx* ctx = s->ctx;
+  Timer timer;
+  const size_t chunk = std::min<size_t>(std::max<size_t>(n, 1), std::min<uint64_t>(ctx->max_batch_paths, 1u << 22));
+  const bool deep = max_depth > 16;
+  if (int rc = ensure_workspace(ctx, chunk, deep, true)) return rc;
+  if (int rc = ctx->rays.reserve(chunk * sizeof(rtmi_ray))) return rc;
+  if (int rc = ctx->spectra_out.reserve(chunk * RT_NBINS * sizeof(float))) return rc;
+  DeviceStats* ds = ctx->stats.as<DeviceStats>();
+  HIP_TRY(hipMemset(ds, 0, sizeof *ds));
+  s->counting = false;
+  KernelClock clock;
+  uint32_t launches = 0, batches = 0;
+  for (size_t at = 0; at < n; at += chunk) {
+    const size_t m = std::min(chunk, n - at);
+    HIP_TRY(hipMemcpy(ctx->rays.p, rays + at, m * sizeof(rtmi_ray), hipMemcpyHostToDevice));
+    BatchDesc b{};
+    b.integrator = integrator; b.max_depth = max_depth; b.seed = seed;
+    b.sample0 = sample_index; b.n_samples = 1;
+    b.rays = ctx->rays.as<double>(); b.n_rays = uint32_t(m); b.pixel_base = pixel_base + uint32_t(at);
+    if (int rc = run_batch(s, b, m, ctx->spectra_out.as<float>(), nullptr, clock, launches)) return rc;
+    HIP_TRY(hipMemcpy(spectra + at * RT_NBINS, ctx->spectra_out.p, m * RT_NBINS * sizeof(float), hipMemcpyDeviceToHost));
+    ++batches;
+  }
+  if (stats) {
+    DeviceStats h;
+    HIP_TRY(hipMemcpy(&h, ds, sizeof h, hipMemcpyDeviceToHost));
+    std::memset(stats, 0, sizeof *stats);
+    stats->segments = n + h.bounce_segments; stats->paths = n;
+    stats->ms_total = timer.ms(); stats->launches = launches; stats->batches = batches;
+  }
+  return RTMI_OK;
+}
+
+// ================================================================================ render
+
+extern "C" int rtmi_render_accumulate(rtmi_scene* s, const rtmi_camera* cam, const rtmi_render_params* p, float* dev_xyz_sum,
+                                      void* stream_, rtmi_stats* stats) {
+  if (int rc = check_scene(s)) return rc;
+  if (!cam || !p || !dev_xyz_sum) return fail(RTMI_BAD_ARG, "NULL argument");
+  if (cam->width == 0 || cam->height == 0) return fail(RTMI_BAD_ARG, "camera resolution %ux%u", cam->width, cam->height);
+  if (uint64_t(cam->width) * cam->height >= (1ull << 32)) return fail(RTMI_UNSUPPORTED, "image too large");
+  if (p->integrator > RTMI_INT_NORMAL) return fail(RTMI_BAD_ARG, "unknown integrator %u", p->integrator);
+  if (p->max_depth > RTMI_MAX_DEPTH) return fail(RTMI_UNSUPPORTED, "max_depth %u > %d", p->max_depth, RTMI_MAX_DEPTH);
+  if (p->spp == 0) return fail(RTMI_BAD_ARG, "spp is 0");
+  const uint32_t s_begin = p->sample_end ? p->sample_begin : 0, s_end = p->sample_end ? p->sample_end : p->spp;
+  if (s_begin > s_end || s_end > p->spp) return fail(RTMI_BAD_ARG, "sample range [%u,%u) outside [0,%u)", s_begin, s_end, p->spp);
+  const uint32_t T = p->tile_size ? p->tile_size : 16;
+  if (T % kPixelBlock != 0 || T > 1024) return fail(RTMI_BAD_ARG, "tile_size %u must be a multiple of %u", T, kPixelBlock);
+  if (p->tile_world && p->tile_rank >= p->tile_world) return fail(RTMI_BAD_ARG, "tile_rank %u >= tile_world %u", p->tile_rank, p->tile_world);
+  rtmi_ctx* ctx = s->ctx;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  Timer timer;
+
+  const uint32_t tiles_x = (cam->width + T - 1) / T, tiles_y = (cam->height + T - 1) / T;
+  std::vector<uint32_t> tiles;
+  uint64_t my_pixels = 0;
+  for (uint32_t k = 0; k < tiles_x * tiles_y; ++k) {
+    if (p->tile_world && k % p->tile_world != p->tile_rank) continue;
+    tiles.push_back(k);
+    const uint32_t x0 = (k / tiles_y) * T, y0 = (k % tiles_y) * T;
+    my_pixels += uint64_t(std::min(T, cam->width - x0)) * std::min(T, cam->height - y0);
+  }
+  const uint32_t n_samples = s_end - s_begin;
+  s->pending = rtmi_stats{};
+  s->pending.paths = my_pixels * n_samples;
+  s->pending.segments = my_pixels * n_samples;  // primary rays; bounce rays are added from the device counters
+  s->counting = (p->flags & RTMI_FLAG_COUNT_TRAVERSAL) != 0;
+  if (tiles.empty() || n_samples == 0) { if (stats) *stats = s->pending; return RTMI_OK; }
+
+  const uint64_t per_tile = uint64_t(T) * T;
+  const uint64_t cap = std::max<uint64_t>(ctx->max_batch_paths, per_tile);
+  const uint32_t tiles_per_batch = uint32_t(std::min<uint64_t>(tiles.size(), cap / per_tile));
+  const uint32_t samples_per_batch = uint32_t(std::min<uint64_t>(n_samples, std::max<uint64_t>(1, cap / (tiles_per_batch * per_tile))));
+  const size_t batch_paths = size_t(tiles_per_batch) * per_tile * samples_per_batch;
+  const bool deep = p->integrator == RTMI_INT_RANDOM_WALK && p->max_depth > 16;
+  if (int rc = ensure_workspace(ctx, batch_paths, deep, p->integrator == RTMI_INT_RANDOM_WALK && p->max_depth > 1)) return rc;
+  if (int rc = ctx->tiles.reserve(tiles.size() * sizeof(uint32_t))) return rc;
+  HIP_TRY(hipMemcpyAsync(ctx->tiles.p, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipStreamSynchronize(stream));  // `tiles` is about to go out of scope
+  HIP_TRY(hipMemsetAsync(ctx->stats.p, 0, sizeof(DeviceStats), stream));
+
+  KernelClock clock;
+  clock.on = (p->flags & RTMI_FLAG_TIME_KERNELS) != 0;
+  clock.stream = stream;
+  uint32_t launches = 0, batches = 0;
+  double kernel_ms = 0.0;
+  for (size_t t0 = 0; t0 < tiles.size(); t0 += tiles_per_batch) {
+    const uint32_t nt = uint32_t(std::min<size_t>(tiles_per_batch, tiles.size() - t0));
+    for (uint32_t s0 = s_begin; s0 < s_end; s0 += samples_per_batch) {
+      BatchDesc b{};
+      b.cam = to_dev_camera(*cam);
+      b.tile_list = ctx->tiles.as<uint32_t>() + t0; b.n_tiles = nt; b.tile_size = T; b.tiles_y = tiles_y;
+      b.n_local_pixels = uint32_t(nt * per_tile);
+      b.sample0 = s0; b.n_samples = std::min(samples_per_batch, s_end - s0);
+      b.integrator = p->integrator; b.max_depth = p->max_depth; b.seed = p->seed;
+      const size_t n_paths = size_t(b.n_local_pixels) * b.n_samples;
+      if (int rc = run_batch(s, b, n_paths, nullptr, stream, clock, launches)) return rc;
+      float* contrib = ctx->contrib.as<float>();
+      launch_resolve(b, TraceOutputs{contrib, contrib + n_paths, contrib + 2 * n_paths, nullptr}, dev_xyz_sum, stream);
+      HIP_TRY(hipGetLastError());
+      if (clock.on) kernel_ms += clock.drain();
+      ++batches;
+    }
+  }
+  s->pending.launches = launches; s->pending.batches = batches; s->pending.ms_kernels = kernel_ms;
+  s->pending.ms_total = timer.ms();
+  if (stats) {
+    if (clock.on || s->counting) return rtmi_render_collect_stats(s, stream_, stats);
+    *stats = s->pending;
+  }
+  return RTMI_OK;
+}
+
+extern "C" int rtmi_render_collect_stats(rtmi_scene* s, void* stream_, rtmi_stats* stats) {
+  if (int rc = check_scene(s)) return rc;
+  if (!stats) return fail(RTMI_BAD_ARG, "stats is NULL");
+  HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream_)));
+  *stats = s->pending;
+  if (s->ctx->stats.p) {
+    DeviceStats h;
+    HIP_TRY(hipMemcpy(&h, s->ctx->stats.p, sizeof h, hipMemcpyDeviceToHost));
+    stats->segments += h.bounce_segments;
+    stats->nodes_visited = h.trav.nodes; stats->prims_tested = h.trav.prims;
+  }
+  return RTMI_OK;
+}
+
+extern "C" int rtmi_tonemap(rtmi_ctx* ctx, const float* dev_xyz_sum, uint32_t spp, uint32_t width, uint32_t height,
+                            uint8_t* dev_rgb8, void* stream) {
+  if (!ctx || !dev_xyz_sum || !dev_rgb8) return fail(RTMI_BAD_ARG, "NULL argument");
+  if (spp == 0) return fail(RTMI_BAD_ARG, "spp is 0");
+  if (int rc = bind(ctx)) return rc;
+  launch_tonemap(dev_xyz_sum, spp, width * height, dev_rgb8, static_cast<hipStream_t>(stream));
+  HIP_TRY(hipGetLastError());
+  return RTMI_OK;
+}
+
+extern "C" int rtmi_render(rtmi_scene* s, const rtmi_camera* cam, const rtmi_render_params* p, uint8_t* host_rgb8,
+                           float* host_xyz, rtmi_stats* stats) {
+  if (int rc = check_scene(s)) return rc;
+  if (!cam || !p) return fail(RTMI_BAD_ARG, "NULL argument");
+  if (!host_rgb8 && !host_xyz) return fail(RTMI_BAD_ARG, "no output buffer");
+  rtmi_ctx* ctx = s->ctx;
+  Timer timer;
+  const size_t n_pix = size_t(cam->width) * cam->height;
+  if (int rc = ctx->image.reserve(n_pix * 3 * sizeof(float) + n_pix * 3)) return rc;
+  float* xyz = ctx->image.as<float>();
+  uint8_t* rgb8 = reinterpret_cast<uint8_t*>(xyz + n_pix * 3);
+  HIP_TRY(hipMemset(xyz, 0, n_pix * 3 * sizeof(float)));
+  rtmi_stats local{};
+  if (int rc = rtmi_render_accumulate(s, cam, p, xyz, nullptr, &local)) return rc;
+  if (int rc = rtmi_render_collect_stats(s, nullptr, &local)) return rc;
+  if (host_rgb8) {
+    if (int rc = rtmi_tonemap(ctx, xyz, p->spp, cam->width, cam->height, rgb8, nullptr)) return rc;
+    HIP_TRY(hipMemcpy(host_rgb8, rgb8, n_pix * 3, hipMemcpyDeviceToHost));
+  }
+  if (host_xyz) {
+    HIP_TRY(hipMemcpy(host_xyz, xyz, n_pix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    const float inv = float(p->spp);
+    for (size_t i = 0; i < n_pix * 3; ++i) host_xyz[i] /= inv;
+  }
+  local.ms_total = timer.ms();
+  if (stats) *stats = local;
+  return RTMI_OK;
+}

@@ -1,0 +1,52 @@
+"""Builds each test workload twice: as an oracle scene (spectra from the oracle) and, on request,
+as a library scene (spectra from librtmi.so), so the two sides share nothing but the numbers."""
+import ctypes as C
+
+import numpy as np
+
+import _oracle as O
+from raytracing_amd import scenes
+
+
+def oracle_scene(recipe, hit_rule=O.HIT_FIRST_INDEX, **kw):
+    b, cam_args = recipe(from_rgb=O.from_rgb, **kw)
+    return O.Scene(*b.arrays(), hit_rule=hit_rule), O.camera(*cam_args), cam_args
+
+
+def library_scene(ctx, recipe, hit_rule=0, **kw):
+    from raytracing_amd import api
+    b, cam_args = recipe(from_rgb=None, **kw)
+    return api.Scene(ctx, *b.arrays(), hit_rule=hit_rule), api.camera_new(*cam_args), cam_args
+
+
+def primary_rays(cam, step=1):
+    """Pixel-centre rays (jitter 0) from the oracle's camera."""
+    w, h = cam.width, cam.height
+    xs, ys = np.arange(0, w, step), np.arange(0, h, step)
+    rays = np.zeros(len(xs) * len(ys), dtype=O.RAY_DT)
+    r = O.Ray()
+    k = 0
+    for y in ys:
+        for x in xs:
+            O.lib().ref_camera_get_ray(C.byref(cam), float(x), float(y), C.byref(r))
+            rays["o"][k], rays["d"][k] = list(r.o), list(r.d)
+            k += 1
+    return rays
+
+
+def random_rays(n, seed, center=(0.0, 0.0, 1.0), radius=6.0, spread=2.0):
+    """Rays from points on a sphere around the scene towards points near its centre."""
+    rng = np.random.default_rng(seed)
+    v = rng.normal(size=(n, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    o = np.asarray(center) + radius * v
+    target = np.asarray(center) + rng.uniform(-spread, spread, size=(n, 3))
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros(n, dtype=O.RAY_DT)
+    rays["o"], rays["d"] = o, d
+    return rays
+
+
+def small_mesh_scene(from_rgb=None, n_lat=24, n_lon=48, width=160, height=90):
+    return scenes.synthetic_mesh_scene(from_rgb, n_lat=n_lat, n_lon=n_lon, width=width, height=height)
