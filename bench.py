@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X: Mpath-segments/s, whole job.
+
+One "step" = one full render of the workload (every pixel, every sample, depth-10 random walk)
+from a scene that is already resident in HBM, including the merge of the per-rank buffers and the
+tone mapping. With N > 1 ranks (torch.distributed over RCCL, one process per GPU) every rank
+renders its own `spp` samples per pixel of an N*spp job (sample-range partition, weak scaling) and
+one reduce merges the per-pixel XYZ sums. Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, ~8 TB/s
+STATE_BYTES = 80             # one path-state record: 6 f64 + 4 u32 + 16 chain bytes (read once, written once per bounce)
+NODE_BYTES, TRI_BYTES = 64, 80
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: Suzanne (968 triangles) + emitter + ground spheres, 1920x1080, 64 spp
+    "suzanne_1080p_64spp": dict(recipe="scene2", width=1920, height=1080, spp=64, depth=10),
+    "suzanne_specular_1080p_64spp": dict(recipe="scene2", width=1920, height=1080, spp=64, depth=10, specular_mesh=True),
+    "scene1_400x225_100spp": dict(recipe="scene1", width=400, height=225, spp=100, depth=10),
+    "scene3_720p_100spp": dict(recipe="scene3", width=1280, height=720, spp=100, depth=10),
+    "mesh1m_4k_16spp": dict(recipe="synthetic_mesh_scene", width=3840, height=2160, spp=16, depth=10),
+}
+
+
+def build_scene(ctx, w, hit_rule, from_rgb=None, library=True):
+    from raytracing_amd import api, scenes
+    kw = {k: v for k, v in w.items() if k in ("width", "height", "specular_mesh")}
+    builder, cam_args = getattr(scenes, w["recipe"])(from_rgb=from_rgb, **kw)
+    if library:
+        return api.Scene(ctx, *builder.arrays(), hit_rule=hit_rule), api.camera_new(*cam_args)
+    return builder, cam_args
+
+
+def cpu_baseline(w, hit_rule, spp_sample, threads):
+    """The CPU oracle (linear scans, the reference's algorithm) on the first `spp_sample` samples per
+    pixel of the same scene and camera, on this machine's host cores."""
+    import _oracle as O
+    builder, cam_args = build_scene(None, w, hit_rule, from_rgb=O.from_rgb, library=False)
+    scene = O.Scene(*builder.arrays(), hit_rule=hit_rule)
+    cam = O.camera(*cam_args)
+    _, _, _, st = scene.render(cam, O.INT_RANDOM_WALK, w["depth"], w["spp"], seed=0, sample_range=(0, spp_sample),
+                               threads=threads, want_lin=False)
+    return st.segments / st.seconds / 1e6, st.seconds, st.segments
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="suzanne_1080p_64spp", choices=sorted(WORKLOADS))
+    ap.add_argument("--rule", default="first_index", choices=["first_index", "nearest"])
+    ap.add_argument("--partition", default="samples", choices=["samples", "tiles"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=0, help="samples per pixel of the CPU baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import api, parallel, _lib as L
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" %
+                         (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    w = WORKLOADS[args.workload]
+    hit_rule = L.HIT_FIRST_INDEX if args.rule == "first_index" else L.HIT_NEAREST
+    ctx = api.Context(local_rank)
+    scene, cam = build_scene(ctx, w, hit_rule)
+    width, height, spp, depth = cam.width, cam.height, w["spp"], w["depth"]
+    spp_job = spp * world if args.partition == "samples" else spp     # weak scaling in samples
+    stream = torch.cuda.current_stream().cuda_stream
+    acc = torch.zeros(height * width * 3, dtype=torch.float32, device=device)
+    rgb8 = torch.zeros(height * width * 3, dtype=torch.uint8, device=device)
+    share = parallel.rank_share(args.partition, spp_job, rank, world)
+
+    def step(flags=0):
+        acc.zero_()
+        p = api.render_params(L.INT_RANDOM_WALK, depth, spp_job, seed=0, flags=flags, **share)
+        scene.render_accumulate(cam, p, acc.data_ptr(), stream)
+        parallel.merge_sums(acc, 0)
+        if rank == 0:
+            ctx.tonemap(acc.data_ptr(), spp_job, width, height, rgb8.data_ptr(), stream)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    # one instrumented step: exact traversal counts for the algorithmic-bytes model (not timed)
+    step(L.FLAG_COUNT_TRAVERSAL)
+    counted = scene.collect_stats(stream)
+    fence()
+
+    kernel_ms, launches, segments = 0.0, 0, 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(L.FLAG_TIME_KERNELS)             # HIP events around every closest-hit launch, on `stream`
+        st = scene.collect_stats(stream)
+        kernel_ms += st["ms_kernels"]; launches += st["launches"]; segments += st["segments"]
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed, float(segments), kernel_ms, float(launches)], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+    total_segments = float(t[1])
+
+    if rank == 0:
+        seg_per_step = counted["segments"]
+        nodes_per_seg = counted["nodes_visited"] / max(1, seg_per_step)
+        tris_per_seg = counted["prims_tested"] / max(1, seg_per_step)
+        bytes_per_seg = 2 * STATE_BYTES + nodes_per_seg * NODE_BYTES + tris_per_seg * TRI_BYTES
+        avg_launch_ms = kernel_ms / max(1, launches)
+        seg_per_launch = segments / max(1, launches)
+        achieved_gbs = (seg_per_launch * bytes_per_seg) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        traffic = None
+        tfile = ROOT / "profiles" / "hbm_traffic.json"
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get(args.workload, {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpath-segments/sec (whole node)",
+            "value": total_segments / elapsed / 1e6,
+            "unit": "Mseg/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak" if args.partition == "samples" else "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "width": width, "height": height, "spp_per_gpu": spp if args.partition == "samples" else None,
+                       "spp_job": spp_job, "max_depth": depth, "integrator": "RandomWalk", "hit_rule": args.rule,
+                       "partition": args.partition, "mesh_triangles": scene.info()["n_mesh_triangles"],
+                       "segments_per_step_per_gpu": seg_per_step},
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "bounce_kernel", "launches": launches, "avg_launch_ms": avg_launch_ms,
+                         "bytes_per_segment": bytes_per_seg, "nodes_per_segment": nodes_per_seg,
+                         "triangles_per_segment": tris_per_seg, "segments_per_launch": seg_per_launch},
+        }
+        if not args.no_cpu_baseline:
+            threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+            cpu_spp = args.cpu_spp or (1 if w["recipe"] == "synthetic_mesh_scene" else max(1, min(spp, 4)))
+            if w["recipe"] == "synthetic_mesh_scene":
+                out["cpu_baseline"] = None  # linear scans over 1M triangles: minutes per 1e5 segments; not run by default
+            else:
+                v, secs, segs = cpu_baseline(w, hit_rule, cpu_spp, threads)
+                out["cpu_baseline"] = {"value": v, "unit": "Mseg/s", "cores": threads, "kind": "port",
+                                       "sample": "same scene and camera, samples [0,%d) of %d per pixel: %d segments in %.1f s"
+                                                 % (cpu_spp, spp, segs, secs)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

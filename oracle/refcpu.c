@@ -795,14 +795,15 @@ void ref_trace_batch(const ref_scene* s, const ref_ray* rays, size_t n, uint32_t
 typedef struct {
   const ref_scene* s; const ref_camera* c; const ref_render_params* p;
   uint32_t x0, y0, x1, y1, tile, tiles_y, s0, s1;
-  uint8_t* rgb8; float* xyz_ref; float* xyz_lin;
-  uint64_t* seg_per_worker;
+  uint8_t* rgb8; float* xyz_ref; float* xyz_lin; float* xyz_sum;
+  uint64_t* seg_per_worker; uint64_t* pix_per_worker;
 } render_job;
 
 static void render_tile(void* a, size_t item, int worker) {
   render_job* j = (render_job*)a;
   /* tiles enumerated x-major: cartesian_product(0..n_x, 0..n_y) :50 */
   uint32_t tx = (uint32_t)(item / j->tiles_y), ty = (uint32_t)(item % j->tiles_y);
+  if (j->p->tile_world && item % j->p->tile_world != j->p->tile_rank) return;
   uint32_t xa = j->x0 + tx * j->tile, ya = j->y0 + ty * j->tile;
   uint32_t xb = xa + j->tile < j->x1 ? xa + j->tile : j->x1, yb = ya + j->tile < j->y1 ? ya + j->tile : j->y1;
   uint32_t W = j->c->width;
@@ -810,15 +811,19 @@ static void render_tile(void* a, size_t item, int worker) {
   uint64_t segs = 0;
   for (uint32_t x = xa; x < xb; ++x) {
     for (uint32_t y = ya; y < yb; ++y) {                               /* :67 x outer, y inner */
-      float sum[REF_NBINS], lin[3] = {0.0f, 0.0f, 0.0f};
+      float sum[REF_NBINS], lin[3] = {0.0f, 0.0f, 0.0f}, run[3] = {0.0f, 0.0f, 0.0f};
+      size_t pix = (size_t)y * W + x;
       spec_set(sum, 0.0f);
+      /* xyz_sum continues the per-pixel running sum in sample order, as one long sequential sum would */
+      if (j->xyz_sum) { run[0] = j->xyz_sum[pix * 3]; run[1] = j->xyz_sum[pix * 3 + 1]; run[2] = j->xyz_sum[pix * 3 + 2]; }
       for (uint32_t k = j->s0; k < j->s1; ++k) {                       /* :69-78 */
         float smp[REF_NBINS], xyz[3];
         ref_evaluate_pixel_sample(j->s, j->c, j->p, x, y, k, smp, &segs);
         for (int i = 0; i < REF_NBINS; ++i) sum[i] += smp[i];
-        if (j->xyz_lin) {
+        if (j->xyz_lin || j->xyz_sum) {
           ref_to_xyz(smp, xyz);
           lin[0] += xyz[0]; lin[1] += xyz[1]; lin[2] += xyz[2];
+          run[0] += xyz[0]; run[1] += xyz[1]; run[2] += xyz[2];
         }
       }
       float nf = (float)n_samples;
@@ -826,17 +831,18 @@ static void render_tile(void* a, size_t item, int worker) {
       float xyz[3], rgb[3];
       ref_to_xyz(sum, xyz);
       ref_xyz_to_rgb(xyz, rgb);
-      size_t pix = (size_t)y * W + x;
       if (j->rgb8) ref_tonemap(rgb, j->rgb8 + pix * 3);
       if (j->xyz_ref) { j->xyz_ref[pix * 3] = xyz[0]; j->xyz_ref[pix * 3 + 1] = xyz[1]; j->xyz_ref[pix * 3 + 2] = xyz[2]; }
       if (j->xyz_lin) { j->xyz_lin[pix * 3] = lin[0] / nf; j->xyz_lin[pix * 3 + 1] = lin[1] / nf; j->xyz_lin[pix * 3 + 2] = lin[2] / nf; }
+      if (j->xyz_sum) { j->xyz_sum[pix * 3] = run[0]; j->xyz_sum[pix * 3 + 1] = run[1]; j->xyz_sum[pix * 3 + 2] = run[2]; }
+      j->pix_per_worker[worker] += 1;
     }
   }
   j->seg_per_worker[worker] += segs;
 }
 
 void ref_render(const ref_scene* s, const ref_camera* c, const ref_render_params* p, uint8_t* rgb8, float* xyz_ref,
-                float* xyz_lin, ref_stats* stats, int threads) {
+                float* xyz_lin, float* xyz_sum, ref_stats* stats, int threads) {
   if (threads < 1) threads = 1;
   render_job j;
   memset(&j, 0, sizeof j);
@@ -847,8 +853,9 @@ void ref_render(const ref_scene* s, const ref_camera* c, const ref_render_params
   j.s0 = p->sample_end ? p->sample_begin : 0; j.s1 = p->sample_end ? p->sample_end : p->spp;
   uint32_t tiles_x = (j.x1 - j.x0 + j.tile - 1) / j.tile;
   j.tiles_y = (j.y1 - j.y0 + j.tile - 1) / j.tile;
-  j.rgb8 = rgb8; j.xyz_ref = xyz_ref; j.xyz_lin = xyz_lin;
+  j.rgb8 = rgb8; j.xyz_ref = xyz_ref; j.xyz_lin = xyz_lin; j.xyz_sum = xyz_sum;
   j.seg_per_worker = (uint64_t*)calloc((size_t)threads, sizeof(uint64_t));
+  j.pix_per_worker = (uint64_t*)calloc((size_t)threads, sizeof(uint64_t));
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
   pool_run(render_tile, &j, (size_t)tiles_x * j.tiles_y, threads);
@@ -856,9 +863,10 @@ void ref_render(const ref_scene* s, const ref_camera* c, const ref_render_params
   if (stats) {
     stats->segments = 0;
     for (int i = 0; i < threads; ++i) stats->segments += j.seg_per_worker[i];
-    stats->paths = (uint64_t)(j.x1 - j.x0) * (j.y1 - j.y0) * (j.s1 - j.s0);
+    stats->paths = 0;
+    for (int i = 0; i < threads; ++i) stats->paths += j.pix_per_worker[i] * (uint64_t)(j.s1 - j.s0);
     stats->seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     stats->threads = (uint32_t)threads; stats->pad = 0;
   }
-  free(j.seg_per_worker);
+  free(j.seg_per_worker); free(j.pix_per_worker);
 }

@@ -72,6 +72,7 @@ typedef struct {
   uint64_t seed;
   uint32_t sample_begin, sample_end; /* samples [begin,end) of every pixel; end==0 -> [0,spp) */
   uint32_t x0, y0, x1, y1;           /* pixel window; x1==0 -> whole image */
+  uint32_t tile_rank, tile_world;    /* tile k (x-major) is rendered iff k % world == rank; world==0 -> all */
 } ref_render_params;
 
 typedef struct { uint64_t segments; uint64_t paths; double seconds; uint32_t threads; uint32_t pad; } ref_stats;
@@ -132,10 +133,12 @@ void ref_trace_batch(const ref_scene* s, const ref_ray* rays, size_t n, uint32_t
 void ref_evaluate_pixel_sample(const ref_scene* s, const ref_camera* c, const ref_render_params* p,
                                uint32_t x, uint32_t y, uint32_t sample, float out[REF_NBINS], uint64_t* segments);
 /* Full render. rgb8: W*H*3 row-major, y = 0 top. xyz_ref: mean XYZ computed as the
- * reference does (sum 60-bin spectra, divide, then to_XYZ). xyz_lin: mean XYZ computed by
- * converting each sample to XYZ first and summing those in sample order. Either may be NULL. */
+ * reference does (sum 60-bin spectra, divide by the number of samples rendered, then to_XYZ).
+ * xyz_lin: mean XYZ computed by converting each sample to XYZ first and summing those in sample
+ * order; xyz_sum: that sum before the division, ADDED to the buffer's contents (for partitioned
+ * renders). Any output may be NULL; pixels of tiles that are not rendered are left untouched. */
 void ref_render(const ref_scene* s, const ref_camera* c, const ref_render_params* p,
-                uint8_t* rgb8, float* xyz_ref, float* xyz_lin, ref_stats* stats, int threads);
+                uint8_t* rgb8, float* xyz_ref, float* xyz_lin, float* xyz_sum, ref_stats* stats, int threads);
 
 #ifdef __cplusplus
 }

@@ -64,7 +64,8 @@ class Camera(C.Structure):
 class RenderParams(C.Structure):
     _fields_ = [("integrator", C.c_uint32), ("max_depth", C.c_uint32), ("spp", C.c_uint32), ("tile_size", C.c_uint32),
                 ("seed", C.c_uint64), ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32),
-                ("x0", C.c_uint32), ("y0", C.c_uint32), ("x1", C.c_uint32), ("y1", C.c_uint32)]
+                ("x0", C.c_uint32), ("y0", C.c_uint32), ("x1", C.c_uint32), ("y1", C.c_uint32),
+                ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -129,7 +130,7 @@ def lib():
     L.ref_evaluate_pixel_sample.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_uint32,
                                             C.c_uint32, C.c_uint32, f60, C.POINTER(C.c_uint64)]
     L.ref_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
-                             C.c_void_p, C.POINTER(Stats), C.c_int]
+                             C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_int]
     L.ref_spectrum_init()
     _lib = L
     return L
@@ -197,8 +198,8 @@ class Scene:
         return out, seg.value
 
     def render(self, cam, integrator, max_depth, spp, seed=0, sample_range=None, window=None, threads=None,
-               want_lin=True):
-        p = RenderParams(integrator, max_depth, spp, 16, seed, 0, 0, 0, 0, 0, 0)
+               want_lin=True, tile_rank=0, tile_world=0, xyz_sum=None):
+        p = RenderParams(integrator, max_depth, spp, 16, seed, 0, 0, 0, 0, 0, 0, tile_rank, tile_world)
         if sample_range:
             p.sample_begin, p.sample_end = sample_range
         if window:
@@ -209,5 +210,6 @@ class Scene:
         xyz_lin = np.zeros((h, w, 3), dtype=np.float32) if want_lin else None
         st = Stats()
         lib().ref_render(self.handle, C.byref(cam), C.byref(p), rgb8.ctypes.data, xyz_ref.ctypes.data,
-                         xyz_lin.ctypes.data if want_lin else None, C.byref(st), threads or (os.cpu_count() or 1))
+                         xyz_lin.ctypes.data if want_lin else None, xyz_sum.ctypes.data if xyz_sum is not None else None,
+                         C.byref(st), threads or (os.cpu_count() or 1))
         return rgb8, xyz_ref, xyz_lin, st
