@@ -9,8 +9,11 @@ from pathlib import Path
 
 import numpy as np
 
+import os
+
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "librtmi.so"
+# RTMI_LIB selects another build of the same library (A/B experiments); the default is the in-tree one.
+LIB_PATH = Path(os.environ["RTMI_LIB"]).resolve() if os.environ.get("RTMI_LIB") else PKG / "librtmi.so"
 
 NBINS = 60
 MISS = 0xFFFFFFFF

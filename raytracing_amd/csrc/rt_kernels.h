@@ -22,6 +22,19 @@ struct PathQueue {
 constexpr int kBlock = 256;            // 4 waves of 64
 constexpr uint32_t kPixelBlock = 8;    // a wave covers an 8x8 pixel block of its tile
 
+// A queue is split into kShards regions, each with its own fill counter on its own 128-byte
+// line: one returning atomic per wave on a single word saturates at about 90 atomics per
+// microsecond chip-wide, which capped the whole kernel. Work is dealt in chunks of kBlock
+// paths; the survivors of chunk c go to region c % kShards. A region can never overflow:
+// it receives at most ceil(total_chunks / kShards) chunks of at most kBlock survivors each.
+constexpr uint32_t kShards = 64;
+constexpr uint32_t kCountStride = 32;  // in uint32 units: one counter per 128-byte line
+inline uint32_t region_chunks(size_t max_paths) {
+  const size_t chunks = (max_paths + kBlock - 1) / kBlock + kShards;
+  return uint32_t((chunks + kShards - 1) / kShards);
+}
+inline size_t queue_entries(size_t max_paths) { return size_t(region_chunks(max_paths)) * kBlock * kShards; }
+
 // One batch of primary paths: samples [sample0, sample0+n_samples) of the pixels of a run of
 // tiles. Path slot = sample_local * n_local_pixels + local_pixel.
 struct BatchDesc {
@@ -49,18 +62,20 @@ struct TraversalCounters { unsigned long long nodes, prims; };
 void upload_constants(const SpectrumTables& t);
 
 // Bounce 0: generates the camera rays of the batch (or reads caller rays), finds the closest
-// hit, shades, and appends surviving paths to `out` (count in *out_count).
-void launch_primary(const DevScene& sc, const BatchDesc& b, PathQueue out, uint32_t* out_count, TraceOutputs o,
-                    TraversalCounters* counters, hipStream_t s);
-// Bounce k > 0: consumes *in_count (<= max_in) paths from `in`.
-void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const uint32_t* in_count, uint32_t max_in,
-                   PathQueue out, uint32_t* out_count, TraceOutputs o, TraversalCounters* counters, hipStream_t s);
+// hit, shades, and appends surviving paths to `out`. out_counts: kShards counters, kCountStride
+// apart, zeroed by the caller. region_entries = region_chunks(max_paths) * kBlock for both queues.
+void launch_primary(const DevScene& sc, const BatchDesc& b, PathQueue out, uint32_t* out_counts, uint32_t region_entries,
+                    TraceOutputs o, TraversalCounters* counters, hipStream_t s);
+// Bounce k > 0: consumes the paths of `in` (fill counters in_counts), at most max_in in total.
+void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const uint32_t* in_counts, uint32_t max_in,
+                   PathQueue out, uint32_t* out_counts, uint32_t region_entries, TraceOutputs o,
+                   TraversalCounters* counters, hipStream_t s);
 // rays: n x {o[3], d[3]} doubles; hits: n x rtmi_hit (64 bytes); both device memory.
 void launch_intersect(const DevScene& sc, const void* rays, size_t n, void* hits, TraversalCounters* counters, hipStream_t s);
 // Adds the batch's per-slot contributions into the per-pixel sums, in sample order.
 void launch_resolve(const BatchDesc& b, TraceOutputs o, float* xyz_sum, hipStream_t s);
-// *total += counts[0] + ... + counts[n-1]
-void launch_sum_counts(const uint32_t* counts, uint32_t n, unsigned long long* total, hipStream_t s);
+// *total += every fill counter of n_levels consecutive queue levels
+void launch_sum_counts(const uint32_t* counts, uint32_t n_levels, unsigned long long* total, hipStream_t s);
 void launch_tonemap(const float* xyz_sum, uint32_t spp, uint32_t n_pixels, uint8_t* rgb8, hipStream_t s);
 
 }  // namespace rtmi

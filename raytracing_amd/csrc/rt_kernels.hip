@@ -53,7 +53,11 @@ __device__ __forceinline__ double dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
   return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+#ifdef RT_EXP_RCP_NORMALIZE
+__device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0 / sqrt(dot(a, a))); }
+#else
 __device__ __forceinline__ V3 normalize(V3 a) { return a / sqrt(dot(a, a)); }  // Ray::new, src/geometry/ray.rs:16
+#endif
 __device__ __forceinline__ V3 ld3(const double* p) { return mk(p[0], p[1], p[2]); }
 
 // row-major 3x4 affine map applied to a point / a vector / transposed linear part to a vector
@@ -163,7 +167,7 @@ struct MeshHit { double t, t_raw; uint32_t index; uint32_t slot; };
 // winner are skipped, distance never prunes. RULE = RT_HIT_NEAREST returns the smallest t,
 // ties to the smaller index. The traversal stack lives in LDS, one column per lane.
 template <int RULE, bool COUNT>
-__device__ __forceinline__ bool mesh_closest(const BvhNode* __restrict__ nodes, const DevMeshTri* __restrict__ tris,
+__device__ __forceinline__ bool mesh_closest(const uint4* __restrict__ nodes, const DevMeshTri* __restrict__ tris,
                                              V3 o, V3 d, uint32_t* stack, MeshHit& best, uint32_t& n_nodes,
                                              uint32_t& n_prims) {
   const V3 invd = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
@@ -196,7 +200,7 @@ __device__ __forceinline__ bool mesh_closest(const BvhNode* __restrict__ nodes, 
       cur = stack[(--sp) * kBlock];
       continue;
     }
-    const uint4* np = reinterpret_cast<const uint4*>(nodes + cur);
+    const uint4* np = nodes + size_t(cur) * 4;   // 64-byte node = 4 x 16 bytes, from LDS when the tree is staged
     const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
     if (COUNT) ++n_nodes;
     const float lo0[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
@@ -235,8 +239,8 @@ struct Hit {
 // strict '<' so the earlier object keeps a tie. The hit point and normal are formed once,
 // for the winner only.
 template <int RULE, bool COUNT>
-__device__ __forceinline__ bool closest_hit(const DevScene& sc, V3 o, V3 d, uint32_t* stack, Hit& hit,
-                                            uint32_t& n_nodes, uint32_t& n_prims) {
+__device__ __forceinline__ bool closest_hit(const DevScene& sc, const uint4* __restrict__ node_words, V3 o, V3 d,
+                                            uint32_t* stack, Hit& hit, uint32_t& n_nodes, uint32_t& n_prims) {
   bool found = false;
   double best_t = 0.0, best_raw = 0.0;
   uint32_t best_obj = 0, best_prim = 0, best_slot = 0;
@@ -253,7 +257,7 @@ __device__ __forceinline__ bool closest_hit(const DevScene& sc, V3 o, V3 d, uint
       ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, t_raw, t);
     } else {
       MeshHit mh;
-      ok = mesh_closest<RULE, COUNT>(sc.nodes + ob.root, sc.mesh_tris + ob.first, o, dn, stack, mh, n_nodes, n_prims);
+      ok = mesh_closest<RULE, COUNT>(node_words + size_t(ob.root) * 4, sc.mesh_tris + ob.first, o, dn, stack, mh, n_nodes, n_prims);
       t = mh.t; t_raw = mh.t_raw; prim = mh.index; slot = mh.slot;
     }
     if (ok && (!found || t < best_t)) {
@@ -308,6 +312,10 @@ __device__ __forceinline__ uint32_t chain_get(const Chain& c, uint32_t k) {
 // (src/spectrum/mod.rs:590-609). Exact binary32 products and sums, no contraction.
 __device__ __forceinline__ void emit_sample(const float* __restrict__ spectra, uint32_t emitted_row, const Chain& chain,
                                             uint32_t n_chain, float xyz[3], float* spectrum_out) {
+#ifdef RT_EXP_NO_EMIT
+  xyz[0] = xyz[1] = xyz[2] = float(emitted_row + n_chain + chain.a.x);
+  return;
+#endif
   float x = 0.0f, y = 0.0f, z = 0.0f;
   const float4* table = reinterpret_cast<const float4*>(spectra);
   for (int q = 0; q < RT_NBINS / 4; ++q) {
@@ -404,6 +412,20 @@ __device__ __forceinline__ bool local_pixel_to_xy(const BatchDesc& b, uint32_t l
   return x < b.cam.width && y < b.cam.height;
 }
 
+// Dynamic LDS of the traversal kernels: [BVH nodes, when they are staged][traversal stacks].
+// Small trees (sc.lds_nodes > 0) are copied into LDS once per workgroup: a node fetch then costs
+// an LDS read instead of an L2 round trip, which is what a long first-index traversal waits on.
+template <bool STAGED>
+__device__ __forceinline__ const uint4* stage_nodes(const DevScene& sc, uint4* lds, uint32_t*& stack) {
+  const uint32_t words = STAGED ? sc.lds_nodes * 4 : 0;
+  stack = reinterpret_cast<uint32_t*>(lds + words) + threadIdx.x;
+  const uint4* src = reinterpret_cast<const uint4*>(sc.nodes);
+  if (!STAGED) return src;
+  for (uint32_t i = threadIdx.x; i < words; i += kBlock) lds[i] = src[i];
+  __syncthreads();
+  return lds;
+}
+
 // ------------------------------------------------------------------------------- the bounce kernel
 
 // One bounce for every path of a queue. PRIMARY: the path starts here (camera ray from the
@@ -411,21 +433,55 @@ __device__ __forceinline__ bool local_pixel_to_xy(const BatchDesc& b, uint32_t l
 //   miss / black material / depth exhausted : the path ends, contributing nothing
 //   emitter                                 : the path ends, contributing Le * (chain product)
 //   Lambertian / specular                   : the path continues into `out`
-template <bool PRIMARY, int RULE, bool COUNT>
+template <bool PRIMARY, int RULE, bool COUNT, bool STAGED>
 __global__ void __launch_bounds__(kBlock)
-bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_count, uint32_t max_in,
-              PathQueue out, uint32_t* __restrict__ out_count, TraceOutputs o, TraversalCounters* counters) {
-  extern __shared__ uint32_t lds_stack[];
-  uint32_t* stack = lds_stack + threadIdx.x;
+bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_counts, uint32_t region_entries,
+              PathQueue out, uint32_t* __restrict__ out_counts, TraceOutputs o, TraversalCounters* counters) {
+  extern __shared__ uint4 lds_dynamic[];
+  __shared__ uint32_t s_chunk_prefix[kShards + 1];  // chunks of kBlock paths before each input region
+  __shared__ uint32_t s_region_fill[kShards];
+  uint32_t* stack;
+  const uint4* node_words = stage_nodes<STAGED>(sc, lds_dynamic, stack);
   const bool deep = b.max_depth > 16;
-  uint32_t n;
-  if (PRIMARY) n = b.rays ? b.n_rays : b.n_local_pixels * b.n_samples;
-  else { n = *in_count; n = n < max_in ? n : max_in; }
+  uint32_t n_chunks;
+  if (PRIMARY) {
+    const uint32_t n = b.rays ? b.n_rays : b.n_local_pixels * b.n_samples;
+    n_chunks = (n + kBlock - 1) / kBlock;
+  } else {
+    // the input queue is kShards regions; number its chunks region after region
+    if (threadIdx.x < kShards) {
+      uint32_t fill = in_counts[threadIdx.x * kCountStride];
+      fill = fill < region_entries ? fill : region_entries;
+      uint32_t scan = (fill + kBlock - 1) / kBlock;
+      for (int off = 1; off < int(kShards); off <<= 1) {
+        const uint32_t up = __shfl_up(scan, off);
+        if (int(threadIdx.x) >= off) scan += up;
+      }
+      s_region_fill[threadIdx.x] = fill;
+      s_chunk_prefix[threadIdx.x + 1] = scan;
+      if (threadIdx.x == 0) s_chunk_prefix[0] = 0;
+    }
+    __syncthreads();
+    n_chunks = s_chunk_prefix[kShards];
+  }
   uint32_t n_nodes = 0, n_prims = 0;
 
-  for (uint32_t base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-    const uint32_t idx = base + threadIdx.x;
-    bool active = idx < n;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    uint32_t idx;
+    bool active;
+    if (PRIMARY) {
+      idx = chunk * kBlock + threadIdx.x;
+      active = idx < (b.rays ? b.n_rays : b.n_local_pixels * b.n_samples);
+    } else {
+      uint32_t lo = 0, hi = kShards;          // region r with prefix[r] <= chunk < prefix[r+1]
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_chunk_prefix[mid] <= chunk) lo = mid; else hi = mid;
+      }
+      const uint32_t within = (chunk - s_chunk_prefix[lo]) * kBlock + threadIdx.x;
+      active = within < s_region_fill[lo];
+      idx = lo * region_entries + within;
+    }
     V3 ro = mk(0, 0, 0), rd = mk(1, 0, 0);
     uint32_t pixel = 0, sample = 0, slot = 0, remaining = 0;
     Chain chain;
@@ -469,7 +525,7 @@ bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict
     V3 no = ro, nd = rd;
     if (active) {
       Hit hit;
-      const bool found = closest_hit<RULE, COUNT>(sc, ro, rd, stack, hit, n_nodes, n_prims);
+      const bool found = closest_hit<RULE, COUNT>(sc, node_words, ro, rd, stack, hit, n_nodes, n_prims);
       float xyz[3];
       bool contributes = false;
       float* spectrum_out = o.spectra ? o.spectra + size_t(slot) * RT_NBINS : nullptr;
@@ -516,16 +572,18 @@ bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict
       }
     }
 
-    // wave-level compaction: one ballot, one atomic per wave, survivors packed in lane order
+    // wave-level compaction: one ballot, one atomic per wave on the fill counter of the output
+    // region this chunk feeds, survivors packed in lane order
     const unsigned long long mask = __ballot(alive);
     if (mask) {
       const uint32_t lane = __lane_id();
       const uint32_t leader = uint32_t(__ffsll((long long)mask)) - 1u;
+      const uint32_t region = chunk % kShards;
       uint32_t start = 0;
-      if (lane == leader) start = atomicAdd(out_count, uint32_t(__popcll(mask)));
+      if (lane == leader) start = atomicAdd(out_counts + region * kCountStride, uint32_t(__popcll(mask)));
       start = __shfl(start, int(leader));
       if (alive) {
-        const uint32_t at = start + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+        const uint32_t at = region * region_entries + start + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
         queue_store(out, at, no, nd, pixel, sample, slot, remaining - 1, chain, deep);
       }
     }
@@ -542,17 +600,18 @@ bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict
 struct HitOut { uint32_t obj, prim; double t; double p[3]; double n[3]; };
 static_assert(sizeof(HitOut) == 64, "hit record must be 64 bytes");
 
-template <int RULE, bool COUNT>
+template <int RULE, bool COUNT, bool STAGED>
 __global__ void __launch_bounds__(kBlock)
 intersect_kernel(DevScene sc, const double* __restrict__ rays, size_t n, HitOut* __restrict__ hits, TraversalCounters* counters) {
-  extern __shared__ uint32_t lds_stack[];
-  uint32_t* stack = lds_stack + threadIdx.x;
+  extern __shared__ uint4 lds_dynamic[];
+  uint32_t* stack;
+  const uint4* node_words = stage_nodes<STAGED>(sc, lds_dynamic, stack);
   uint32_t n_nodes = 0, n_prims = 0;
   for (size_t idx = size_t(blockIdx.x) * kBlock + threadIdx.x; idx < n; idx += size_t(gridDim.x) * kBlock) {
     const V3 o = ld3(rays + idx * 6), d = ld3(rays + idx * 6 + 3);
     Hit hit;
     HitOut h;
-    if (closest_hit<RULE, COUNT>(sc, o, d, stack, hit, n_nodes, n_prims)) {
+    if (closest_hit<RULE, COUNT>(sc, node_words, o, d, stack, hit, n_nodes, n_prims)) {
       h.obj = hit.obj; h.prim = hit.prim; h.t = hit.t;
       h.p[0] = hit.p.x; h.p[1] = hit.p.y; h.p[2] = hit.p.z;
       h.n[0] = hit.n.x; h.n[1] = hit.n.y; h.n[2] = hit.n.z;
@@ -584,12 +643,11 @@ __global__ void __launch_bounds__(kBlock) resolve_kernel(BatchDesc b, TraceOutpu
   xyz_sum[pix * 3] = sx; xyz_sum[pix * 3 + 1] = sy; xyz_sum[pix * 3 + 2] = sz;
 }
 
-__global__ void sum_counts_kernel(const uint32_t* counts, uint32_t n, unsigned long long* total) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    unsigned long long s = 0;
-    for (uint32_t i = 0; i < n; ++i) s += counts[i];
-    *total += s;
-  }
+__global__ void sum_counts_kernel(const uint32_t* counts, uint32_t n_levels, unsigned long long* total) {
+  unsigned long long s = 0;
+  for (uint32_t level = 0; level < n_levels; ++level) s += counts[(level * kShards + threadIdx.x) * kCountStride];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if (threadIdx.x == 0) *total += s;
 }
 
 // mean, XYZ -> RGB, clamp, gamma 1/2.2, `(256 * v) as u8` (src/integrators/integrator.rs:79-90,
@@ -620,55 +678,64 @@ inline uint32_t grid_for(size_t n) {
   return uint32_t(blocks < 1 ? 1 : (blocks < cap ? blocks : cap));
 }
 
-inline size_t stack_bytes(const DevScene& sc) { return size_t(sc.stack_entries) * kBlock * sizeof(uint32_t); }
+inline size_t stack_bytes(const DevScene& sc) {
+  return size_t(sc.lds_nodes) * sizeof(BvhNode) + size_t(sc.stack_entries) * kBlock * sizeof(uint32_t);
+}
 
 }  // namespace
 
-#define RTMI_DISPATCH(KERNEL, PRIM, ...)                                                                       \
-  do {                                                                                                         \
-    const bool count_ = counters != nullptr;                                                                   \
-    if (sc.hit_rule == RT_HIT_FIRST_INDEX) {                                                                   \
-      if (count_) hipLaunchKernelGGL((KERNEL<PRIM, RT_HIT_FIRST_INDEX, true>), grid, kBlock, lds, s, __VA_ARGS__);  \
-      else hipLaunchKernelGGL((KERNEL<PRIM, RT_HIT_FIRST_INDEX, false>), grid, kBlock, lds, s, __VA_ARGS__);        \
-    } else {                                                                                                   \
-      if (count_) hipLaunchKernelGGL((KERNEL<PRIM, RT_HIT_NEAREST, true>), grid, kBlock, lds, s, __VA_ARGS__);      \
-      else hipLaunchKernelGGL((KERNEL<PRIM, RT_HIT_NEAREST, false>), grid, kBlock, lds, s, __VA_ARGS__);            \
-    }                                                                                                          \
+// kernel<PRIM, RULE, COUNT, STAGED> chosen from the scene's hit rule, whether traversal counters
+// were asked for, and whether the tree is small enough to live in LDS
+#define RTMI_DISPATCH(KERNEL, PRIM, ...)                                                                    \
+  do {                                                                                                      \
+    const int sel_ = (sc.hit_rule == RT_HIT_NEAREST ? 4 : 0) | (counters ? 2 : 0) | (sc.lds_nodes ? 1 : 0);  \
+    switch (sel_) {                                                                                         \
+      case 0: hipLaunchKernelGGL((KERNEL<PRIM, 0, false, false>), grid, kBlock, lds, s, __VA_ARGS__); break; \
+      case 1: hipLaunchKernelGGL((KERNEL<PRIM, 0, false, true>), grid, kBlock, lds, s, __VA_ARGS__); break;  \
+      case 2: hipLaunchKernelGGL((KERNEL<PRIM, 0, true, false>), grid, kBlock, lds, s, __VA_ARGS__); break;  \
+      case 3: hipLaunchKernelGGL((KERNEL<PRIM, 0, true, true>), grid, kBlock, lds, s, __VA_ARGS__); break;   \
+      case 4: hipLaunchKernelGGL((KERNEL<PRIM, 1, false, false>), grid, kBlock, lds, s, __VA_ARGS__); break; \
+      case 5: hipLaunchKernelGGL((KERNEL<PRIM, 1, false, true>), grid, kBlock, lds, s, __VA_ARGS__); break;  \
+      case 6: hipLaunchKernelGGL((KERNEL<PRIM, 1, true, false>), grid, kBlock, lds, s, __VA_ARGS__); break;  \
+      default: hipLaunchKernelGGL((KERNEL<PRIM, 1, true, true>), grid, kBlock, lds, s, __VA_ARGS__); break;  \
+    }                                                                                                       \
   } while (0)
 
-void launch_primary(const DevScene& sc, const BatchDesc& b, PathQueue out, uint32_t* out_count, TraceOutputs o,
-                    TraversalCounters* counters, hipStream_t s) {
+void launch_primary(const DevScene& sc, const BatchDesc& b, PathQueue out, uint32_t* out_counts, uint32_t region_entries,
+                    TraceOutputs o, TraversalCounters* counters, hipStream_t s) {
   const size_t n = b.rays ? size_t(b.n_rays) : size_t(b.n_local_pixels) * b.n_samples;
   if (n == 0) return;
   const dim3 grid(grid_for(n));
   const size_t lds = stack_bytes(sc);
   PathQueue none{};
-  RTMI_DISPATCH(bounce_kernel, true, sc, b, none, (const uint32_t*)nullptr, 0u, out, out_count, o, counters);
+  RTMI_DISPATCH(bounce_kernel, true, sc, b, none, (const uint32_t*)nullptr, region_entries, out, out_counts, o, counters);
 }
 
-void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const uint32_t* in_count, uint32_t max_in,
-                   PathQueue out, uint32_t* out_count, TraceOutputs o, TraversalCounters* counters, hipStream_t s) {
+void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const uint32_t* in_counts, uint32_t max_in,
+                   PathQueue out, uint32_t* out_counts, uint32_t region_entries, TraceOutputs o,
+                   TraversalCounters* counters, hipStream_t s) {
   if (max_in == 0) return;
-  const dim3 grid(grid_for(max_in));
+  const dim3 grid(grid_for(size_t(max_in) + size_t(kShards) * kBlock));
   const size_t lds = stack_bytes(sc);
-  RTMI_DISPATCH(bounce_kernel, false, sc, b, in, in_count, max_in, out, out_count, o, counters);
+  RTMI_DISPATCH(bounce_kernel, false, sc, b, in, in_counts, region_entries, out, out_counts, o, counters);
 }
 
-template <int RULE, bool COUNT>
-static void launch_intersect_t(const DevScene& sc, const void* rays, size_t n, void* hits, TraversalCounters* counters,
-                               hipStream_t s) {
-  hipLaunchKernelGGL((intersect_kernel<RULE, COUNT>), dim3(grid_for(n)), kBlock, stack_bytes(sc), s, sc,
-                     static_cast<const double*>(rays), n, static_cast<HitOut*>(hits), counters);
-}
-
-void launch_intersect(const DevScene& sc, const void* rays, size_t n, void* hits, TraversalCounters* counters, hipStream_t s) {
+void launch_intersect(const DevScene& sc, const void* rays_, size_t n, void* hits_, TraversalCounters* counters, hipStream_t s) {
   if (n == 0) return;
-  if (sc.hit_rule == RT_HIT_FIRST_INDEX) {
-    if (counters) launch_intersect_t<RT_HIT_FIRST_INDEX, true>(sc, rays, n, hits, counters, s);
-    else launch_intersect_t<RT_HIT_FIRST_INDEX, false>(sc, rays, n, hits, counters, s);
-  } else {
-    if (counters) launch_intersect_t<RT_HIT_NEAREST, true>(sc, rays, n, hits, counters, s);
-    else launch_intersect_t<RT_HIT_NEAREST, false>(sc, rays, n, hits, counters, s);
+  const dim3 grid(grid_for(n));
+  const size_t lds = stack_bytes(sc);
+  const double* rays = static_cast<const double*>(rays_);
+  HitOut* hits = static_cast<HitOut*>(hits_);
+  const int sel = (sc.hit_rule == RT_HIT_NEAREST ? 4 : 0) | (counters ? 2 : 0) | (sc.lds_nodes ? 1 : 0);
+  switch (sel) {
+    case 0: hipLaunchKernelGGL((intersect_kernel<0, false, false>), grid, kBlock, lds, s, sc, rays, n, hits, counters); break;
+    case 1: hipLaunchKernelGGL((intersect_kernel<0, false, true>), grid, kBlock, lds, s, sc, rays, n, hits, counters); break;
+    case 2: hipLaunchKernelGGL((intersect_kernel<0, true, false>), grid, kBlock, lds, s, sc, rays, n, hits, counters); break;
+    case 3: hipLaunchKernelGGL((intersect_kernel<0, true, true>), grid, kBlock, lds, s, sc, rays, n, hits, counters); break;
+    case 4: hipLaunchKernelGGL((intersect_kernel<1, false, false>), grid, kBlock, lds, s, sc, rays, n, hits, counters); break;
+    case 5: hipLaunchKernelGGL((intersect_kernel<1, false, true>), grid, kBlock, lds, s, sc, rays, n, hits, counters); break;
+    case 6: hipLaunchKernelGGL((intersect_kernel<1, true, false>), grid, kBlock, lds, s, sc, rays, n, hits, counters); break;
+    default: hipLaunchKernelGGL((intersect_kernel<1, true, true>), grid, kBlock, lds, s, sc, rays, n, hits, counters); break;
   }
 }
 
@@ -677,8 +744,9 @@ void launch_resolve(const BatchDesc& b, TraceOutputs o, float* xyz_sum, hipStrea
   hipLaunchKernelGGL(resolve_kernel, dim3((b.n_local_pixels + kBlock - 1) / kBlock), kBlock, 0, s, b, o, xyz_sum);
 }
 
-void launch_sum_counts(const uint32_t* counts, uint32_t n, unsigned long long* total, hipStream_t s) {
-  hipLaunchKernelGGL(sum_counts_kernel, dim3(1), 64, 0, s, counts, n, total);
+void launch_sum_counts(const uint32_t* counts, uint32_t n_levels, unsigned long long* total, hipStream_t s) {
+  static_assert(kShards == 64, "sum_counts_kernel reduces one wave of kShards lanes");
+  hipLaunchKernelGGL(sum_counts_kernel, dim3(1), 64, 0, s, counts, n_levels, total);
 }
 
 void launch_tonemap(const float* xyz_sum, uint32_t spp, uint32_t n_pixels, uint8_t* rgb8, hipStream_t s) {

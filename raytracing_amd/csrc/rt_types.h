@@ -84,6 +84,8 @@ struct DevScene {
   uint32_t hit_rule;
   uint32_t stack_entries;     // LDS traversal stack depth per lane
   uint32_t n_spectra;
+  uint32_t lds_nodes;         // > 0: all BVH nodes of the scene (this many) are staged into LDS by every workgroup
+  uint32_t pad;
 };
 
 struct DevCamera {

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -107,7 +108,9 @@ PathQueue carve_queue(void* base, size_t paths, bool deep) {
   return q;
 }
 
-size_t queue_bytes(size_t paths, bool deep) { return paths * (6 * 8 + 4 * 4 + 16 + (deep ? 16 : 0)) + 12 * 256; }
+size_t queue_bytes(size_t entries, bool deep) { return entries * (6 * 8 + 4 * 4 + 16 + (deep ? 16 : 0)) + 12 * 256; }
+constexpr size_t kCountLevelWords = size_t(kShards) * kCountStride;            // uint32 words per queue level
+constexpr size_t kCountBytes = (RT_MAX_DEPTH + 2) * kCountLevelWords * sizeof(uint32_t);
 
 int ensure_workspace(rtmi_ctx* ctx, size_t paths, bool deep, bool want_queues) {
   if (want_queues && (paths > ctx->queue_paths || (deep && !ctx->queue_deep))) {
@@ -115,13 +118,13 @@ int ensure_workspace(rtmi_ctx* ctx, size_t paths, bool deep, bool want_queues) {
     const bool d = deep || ctx->queue_deep;
     for (int i = 0; i < 2; ++i) {
       ctx->queue_mem[i].release();
-      if (int rc = ctx->queue_mem[i].reserve(queue_bytes(p, d))) return rc;
-      ctx->queue[i] = carve_queue(ctx->queue_mem[i].p, p, d);
+      if (int rc = ctx->queue_mem[i].reserve(queue_bytes(queue_entries(p), d))) return rc;
+      ctx->queue[i] = carve_queue(ctx->queue_mem[i].p, queue_entries(p), d);
     }
     ctx->queue_paths = p; ctx->queue_deep = d;
   }
   if (int rc = ctx->contrib.reserve(paths * 3 * sizeof(float))) return rc;
-  if (int rc = ctx->counts.reserve((RT_MAX_DEPTH + 2) * sizeof(uint32_t))) return rc;
+  if (int rc = ctx->counts.reserve(kCountBytes)) return rc;
   if (!ctx->stats.p) {
     if (int rc = ctx->stats.reserve(sizeof(DeviceStats))) return rc;
     HIP_TRY(hipMemset(ctx->stats.p, 0, sizeof(DeviceStats)));
@@ -198,21 +201,23 @@ int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra
   TraceOutputs o{contrib, contrib + n_paths, contrib + 2 * n_paths, spectra_out};
   DeviceStats* ds = ctx->stats.as<DeviceStats>();
   TraversalCounters* counters = sc->counting ? &ds->trav : nullptr;
-  HIP_TRY(hipMemsetAsync(counts, 0, (RT_MAX_DEPTH + 2) * sizeof(uint32_t), stream));
+  const uint32_t depth = b.integrator == RT_INT_RANDOM_WALK ? b.max_depth : 0;
+  // queue level k holds the paths that enter bounce k; its kShards fill counters sit at counts + k * kCountLevelWords
+  HIP_TRY(hipMemsetAsync(counts, 0, (size_t(depth) + 2) * kCountLevelWords * sizeof(uint32_t), stream));
   HIP_TRY(hipMemsetAsync(contrib, 0, n_paths * 3 * sizeof(float), stream));
+  const uint32_t region_entries = region_chunks(ctx->queue_paths) * kBlock;
   clock.begin();
-  launch_primary(sc->dev, b, ctx->queue[0], counts + 1, o, counters, stream);
+  launch_primary(sc->dev, b, ctx->queue[0], counts + kCountLevelWords, region_entries, o, counters, stream);
   clock.end();
   ++launches;
-  const uint32_t depth = b.integrator == RT_INT_RANDOM_WALK ? b.max_depth : 0;
   for (uint32_t k = 1; k < depth; ++k) {
     clock.begin();
-    launch_bounce(sc->dev, b, ctx->queue[(k - 1) & 1], counts + k, uint32_t(n_paths), ctx->queue[k & 1], counts + k + 1, o,
-                  counters, stream);
+    launch_bounce(sc->dev, b, ctx->queue[(k - 1) & 1], counts + k * kCountLevelWords, uint32_t(n_paths), ctx->queue[k & 1],
+                  counts + (k + 1) * kCountLevelWords, region_entries, o, counters, stream);
     clock.end();
     ++launches;
   }
-  if (depth > 1) launch_sum_counts(counts + 1, depth - 1, &ds->bounce_segments, stream);
+  if (depth > 1) launch_sum_counts(counts + kCountLevelWords, depth - 1, &ds->bounce_segments, stream);
   HIP_TRY(hipGetLastError());
   return RTMI_OK;
 }
@@ -401,8 +406,14 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
     objects[i] = dobj;
   }
   const uint32_t stack_entries = nodes.empty() ? 0 : max_depth + 1;
-  if (size_t(stack_entries) * kBlock * sizeof(uint32_t) > 160 * 1024)
-    return fail(RTMI_UNSUPPORTED, "BVH depth %u needs more LDS than a CU has", max_depth);
+  const size_t stack_lds = size_t(stack_entries) * kBlock * sizeof(uint32_t);
+  if (stack_lds > 150 * 1024) return fail(RTMI_UNSUPPORTED, "BVH depth %u needs more LDS than a CU has", max_depth);
+  // Stage the whole tree into LDS only while three workgroups (nodes + stacks each) still fit in a
+  // CU's 160 KB: the kernels are bound by binary64 VALU issue, not by node-fetch latency, so giving
+  // up a resident wave per SIMD for LDS space costs more than the faster fetch returns (measured on
+  // the 613-node Suzanne tree: 2 workgroups/CU with staged nodes ran 8 % slower than 3 without).
+  const size_t node_bytes = nodes.size() * sizeof(BvhNode);
+  const bool stage = !nodes.empty() && 3 * (node_bytes + stack_lds) + 3 * 1024 <= 160 * 1024 && !getenv("RTMI_NO_LDS_NODES");
 
   std::unique_ptr<rtmi_scene> s(new rtmi_scene);
   s->ctx = ctx;
@@ -419,6 +430,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   s->dev.spectra = s->spectra.as<float>();
   s->dev.n_objects = d->n_objects; s->dev.hit_rule = d->hit_rule; s->dev.stack_entries = stack_entries;
   s->dev.n_spectra = uint32_t(spectra.size() / RT_NBINS);
+  s->dev.lds_nodes = stage ? uint32_t(nodes.size()) : 0;
   s->info.n_nodes = uint32_t(nodes.size()); s->info.max_depth = max_depth;
   s->info.n_mesh_triangles = uint32_t(mesh_tris.size()); s->info.n_spectra = s->dev.n_spectra;
   s->info.node_bytes = nodes.size() * sizeof(BvhNode); s->info.triangle_bytes = mesh_tris.size() * sizeof(DevMeshTri);
