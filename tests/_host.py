@@ -1,0 +1,206 @@
+"""ctypes binding of the C++ host layer (raytracing_amd/libraytracer_host.so) + writers for scene files."""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from raytracing_amd import _lib as L
+
+ROOT = Path(__file__).resolve().parent.parent
+HOST_LIB = ROOT / "raytracing_amd" / "libraytracer_host.so"
+CLI = ROOT / "raytracing_amd" / "raytracer"
+
+_host = None
+
+
+def host():
+    global _host
+    if _host is None:
+        L.lib()  # loads the HIP runtime globally, then librtmi.so
+        H = C.CDLL(str(HOST_LIB))
+        H.rth_last_error.restype = C.c_char_p
+        H.rth_scene_load.restype = C.c_void_p
+        H.rth_scene_load.argtypes = [C.c_char_p, C.c_int]
+        H.rth_scene_free.argtypes = [C.c_void_p]
+        H.rth_scene_arrays.argtypes = [C.c_void_p] + [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)] * 4 + [C.POINTER(L.Camera)]
+        H.rth_scene_render.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(L.Stats)]
+        H.rth_save_bmp.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        _host = H
+    return _host
+
+
+class LoadError(RuntimeError):
+    pass
+
+
+class LoadedScene:
+    def __init__(self, toml_path, fan=0):
+        self.handle = host().rth_scene_load(str(toml_path).encode(), fan)
+        if not self.handle:
+            raise LoadError(host().rth_last_error().decode())
+
+    def arrays(self):
+        ptrs = [C.c_void_p() for _ in range(4)]
+        ns = [C.c_uint32() for _ in range(4)]
+        cam = L.Camera()
+        args = []
+        for p, n in zip(ptrs, ns):
+            args += [C.byref(p), C.byref(n)]
+        host().rth_scene_arrays(self.handle, *args, C.byref(cam))
+        out = []
+        for p, n, dt in zip(ptrs, ns, (L.OBJECT_DT, L.SPHERE_DT, L.TRIANGLE_DT, L.MATERIAL_DT)):
+            if n.value:
+                buf = (C.c_char * (n.value * dt.itemsize)).from_address(p.value)
+                out.append(np.frombuffer(buf, dtype=dt).copy())
+            else:
+                out.append(np.zeros(0, dtype=dt))
+        return out, cam
+
+    def render(self, integrator, depth, spp, seed=0, hit_rule=0):
+        _, cam = self.arrays()
+        rgb8 = np.zeros((cam.height, cam.width, 3), dtype=np.uint8)
+        st = L.Stats()
+        if host().rth_scene_render(self.handle, integrator, depth, spp, seed, hit_rule, rgb8.ctypes.data, C.byref(st)):
+            raise RuntimeError(host().rth_last_error().decode())
+        return rgb8, st
+
+    def close(self):
+        if self.handle:
+            host().rth_scene_free(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+
+def write_obj(path, mesh_name, mtl_name, golden="meshes.npz"):
+    """Writes a golden mesh back out as an OBJ file with polygon faces and v/vt/vn style corners."""
+    z = np.load(ROOT / "tests" / "golden" / golden)
+    v, idx, offs = z[mesh_name + "_vertices"], z[mesh_name + "_face_index"], z[mesh_name + "_face_offsets"]
+    lines = ["# written by tests/_host.py", "mtllib %s" % mtl_name, "o Mesh"]
+    lines += ["v %r %r %r" % tuple(float(c) for c in p) for p in v]
+    lines += ["vn 0.0 0.0 1.0", "vt 0.5 0.5", "usemtl M", "s off"]
+    for f in range(len(offs) - 1):
+        lines.append("f " + " ".join("%d/1/1" % (i + 1) for i in idx[offs[f]:offs[f + 1]]))
+    Path(path).write_text("\n".join(lines) + "\n")
+
+
+def write_mtl(path, ka, kd, ks, ke=None, ns=360.0, ni=1.45):
+    lines = ["# written by tests/_host.py", "newmtl M", "Ns %r" % ns, "Ka %r %r %r" % ka, "Kd %r %r %r" % kd, "Ks %r %r %r" % ks]
+    if ke is not None:
+        lines.append("Ke %r %r %r" % ke)
+    lines += ["Ni %r" % ni, "d 1.0", "illum 2", "newmtl Second", "Ka 0.0 0.0 0.0", "Kd 0.0 0.0 0.0", "Ks 0.0 0.0 0.0"]
+    Path(path).write_text("\n".join(lines) + "\n")
+
+
+SCENE1_TOML = """# the stock cube-room scene, numbers as in the reference's scene.toml
+[Camera]
+width = {w}
+height = {h}
+position = [-2.5, 0.0, 2.0]
+focal_distance = 0.1
+field_of_view = 120.0
+rotation = [0.0, 0.5, 0.0]
+
+[[Scene]]
+type = "ModelObj"
+path = "cube.obj"
+
+[[Scene]]
+type = "Sphere"
+center = [0.0, -2.0, 1.0]
+radius = 1.0
+[Scene.material]
+type = "Lambertian"
+albedo = [0.8, 0.2, 0.2]
+
+[[Scene]]
+type = "Sphere"
+center = [0.0, 0.0, 1.0]
+radius = 1.0
+[Scene.material]
+type = "Specular"
+albedo = [0.8, 0.8, 0.8]
+
+[[Scene]]
+type = "Sphere"
+center = [0.0, 1.5, 1.5]
+scale = [1.0, 0.5, 1.5]
+radius = 1.0
+[Scene.material]
+type = "Specular"
+albedo = [0.8, 0.2, 0.2]
+
+[[Scene]]
+type = "Triangle"
+vertices = [
+	[-200.0, -100.0, 0.0],
+	[100.0, 200.0, 0.0],
+	[100.0, -100.0, 0.0]]
+[Scene.material]
+type = "Lambertian"
+albedo = [0.6, 0.5, 0.1]
+
+[[Scene]]
+type = "Triangle"
+vertices = [
+	[-1.0, 1.0, 0.01],
+	[-1.0, 2.0, 0.01],
+	[0.0, 2.0, 0.01]]
+[Scene.material]
+type = "Specular"
+albedo = [0.2, 0.1, 0.9]
+
+[[Scene]]
+type = "Sphere"
+center = [0.0, 0.0, 3.0]
+radius = 0.8
+[Scene.material]
+type = "Emitter"
+albedo = [0.6, 0.6, 0.6]
+"""
+
+SCENE2_TOML = """[Camera]
+width = {w}
+height = {h}
+position = [-2.5, 0.0, 2.0]
+focal_distance = 0.1
+field_of_view = 120.0
+rotation = [0.0, 0.5, 0.0]
+
+[[Scene]]
+type = "ModelObj"
+path = "monkey.obj"
+{override}
+[[Scene]]
+type = "Sphere"
+center = [0.0, -4.0, 4.0]
+radius = 1.5
+[Scene.material]
+type = "Emitter"
+albedo = [1.0, 1.0, 1.0]
+
+[[Scene]]
+type = "Sphere"
+center = [0.0, 0.0, -1000.0]
+radius = 999.5
+[Scene.material]
+type = "Lambertian"
+albedo = [0.376, 0.239, 0.141]
+"""
+
+
+def write_scene1(dirpath, w=400, h=225):
+    d = Path(dirpath)
+    write_obj(d / "cube.obj", "cubo", "cube.mtl")
+    write_mtl(d / "cube.mtl", (1.0, 1.0, 1.0), (0.162632, 0.037185, 0.010680), (0.5, 0.5, 0.5), (0.0, 0.0, 0.0))
+    (d / "scene.toml").write_text(SCENE1_TOML.format(w=w, h=h))
+    return d / "scene.toml"
+
+
+def write_scene2(dirpath, w=850, h=480, specular=False):
+    d = Path(dirpath)
+    write_obj(d / "monkey.obj", "mono", "monkey.mtl")
+    write_mtl(d / "monkey.mtl", (0.8, 0.8, 0.8), (0.8, 0.8, 0.8), (0.8, 0.8, 0.8), None, ns=500.0, ni=1.0)
+    override = '[Scene.material]\ntype = "Specular"\nalbedo = [0.8, 0.8, 0.8]\n' if specular else ""
+    (d / "scene2.toml").write_text(SCENE2_TOML.format(w=w, h=h, override=override))
+    return d / "scene2.toml"
