@@ -52,9 +52,23 @@ struct BatchDesc {
   uint32_t n_rays, pixel_base;
 };
 
+// Paths that ended on an emitter, waiting for their 60-bin product to be formed. Evaluating the
+// product inside the bounce kernel made every wave pay ~1000 instructions whenever one of its 64
+// lanes reached a light; queued, the work runs dense in its own kernel. Same sharded layout as a
+// path queue (kShards regions of emit_region_entries, one fill counter per 128-byte line).
+struct EmitQueue {
+  uint32_t* slot;     // contribution slot, RT_MISS for a reserved-but-unused entry
+  uint32_t* info;     // emitted spectrum row | number of chain entries << 8
+  uint4* chain0;
+  uint4* chain1;      // only when depth > 16
+};
+
 struct TraceOutputs {
   float* contrib_x; float* contrib_y; float* contrib_z;  // per path slot, CIE XYZ of the sample
   float* spectra;                                        // optional: per path slot, 60 bins
+  EmitQueue emit;                                        // used when emit_counts != nullptr
+  uint32_t* emit_counts;
+  uint32_t emit_region_entries;
 };
 
 struct TraversalCounters { unsigned long long nodes, prims; };
@@ -70,6 +84,8 @@ void launch_primary(const DevScene& sc, const BatchDesc& b, PathQueue out, uint3
 void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const uint32_t* in_counts, uint32_t max_in,
                    PathQueue out, uint32_t* out_counts, uint32_t region_entries, TraceOutputs o,
                    TraversalCounters* counters, hipStream_t s);
+// Forms the spectrum / XYZ of every queued emitter hit and writes the path's contribution.
+void launch_emit(const DevScene& sc, TraceOutputs o, bool deep, uint32_t max_entries, hipStream_t s);
 // rays: n x {o[3], d[3]} doubles; hits: n x rtmi_hit (64 bytes); both device memory.
 void launch_intersect(const DevScene& sc, const void* rays, size_t n, void* hits, TraversalCounters* counters, hipStream_t s);
 // Adds the batch's per-slot contributions into the per-pixel sums, in sample order.

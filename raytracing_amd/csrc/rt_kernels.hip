@@ -426,6 +426,36 @@ __device__ __forceinline__ const uint4* stage_nodes(const DevScene& sc, uint4* l
   return lds;
 }
 
+// Numbers the chunks (kBlock entries each) of a sharded queue region after region: fills
+// s_prefix[0..kShards] and s_fill[0..kShards) and returns the total number of chunks.
+__device__ __forceinline__ uint32_t number_chunks(const uint32_t* __restrict__ counts, uint32_t region_entries,
+                                                  uint32_t* s_prefix, uint32_t* s_fill) {
+  if (threadIdx.x < kShards) {
+    uint32_t fill = counts[threadIdx.x * kCountStride];
+    fill = fill < region_entries ? fill : region_entries;
+    uint32_t scan = (fill + kBlock - 1) / kBlock;
+    for (int off = 1; off < int(kShards); off <<= 1) {
+      const uint32_t up = __shfl_up(scan, off);
+      if (int(threadIdx.x) >= off) scan += up;
+    }
+    s_fill[threadIdx.x] = fill;
+    s_prefix[threadIdx.x + 1] = scan;
+    if (threadIdx.x == 0) s_prefix[0] = 0;
+  }
+  __syncthreads();
+  return s_prefix[kShards];
+}
+
+// chunk -> (region, first entry of the chunk inside the region)
+__device__ __forceinline__ uint32_t find_region(const uint32_t* s_prefix, uint32_t chunk) {
+  uint32_t lo = 0, hi = kShards;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (s_prefix[mid] <= chunk) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 // ------------------------------------------------------------------------------- the bounce kernel
 
 // One bounce for every path of a queue. PRIMARY: the path starts here (camera ray from the
@@ -448,21 +478,7 @@ bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict
     const uint32_t n = b.rays ? b.n_rays : b.n_local_pixels * b.n_samples;
     n_chunks = (n + kBlock - 1) / kBlock;
   } else {
-    // the input queue is kShards regions; number its chunks region after region
-    if (threadIdx.x < kShards) {
-      uint32_t fill = in_counts[threadIdx.x * kCountStride];
-      fill = fill < region_entries ? fill : region_entries;
-      uint32_t scan = (fill + kBlock - 1) / kBlock;
-      for (int off = 1; off < int(kShards); off <<= 1) {
-        const uint32_t up = __shfl_up(scan, off);
-        if (int(threadIdx.x) >= off) scan += up;
-      }
-      s_region_fill[threadIdx.x] = fill;
-      s_chunk_prefix[threadIdx.x + 1] = scan;
-      if (threadIdx.x == 0) s_chunk_prefix[0] = 0;
-    }
-    __syncthreads();
-    n_chunks = s_chunk_prefix[kShards];
+    n_chunks = number_chunks(in_counts, region_entries, s_chunk_prefix, s_region_fill);
   }
   uint32_t n_nodes = 0, n_prims = 0;
 
@@ -473,11 +489,7 @@ bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict
       idx = chunk * kBlock + threadIdx.x;
       active = idx < (b.rays ? b.n_rays : b.n_local_pixels * b.n_samples);
     } else {
-      uint32_t lo = 0, hi = kShards;          // region r with prefix[r] <= chunk < prefix[r+1]
-      while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (s_chunk_prefix[mid] <= chunk) lo = mid; else hi = mid;
-      }
+      const uint32_t lo = find_region(s_chunk_prefix, chunk);
       const uint32_t within = (chunk - s_chunk_prefix[lo]) * kBlock + threadIdx.x;
       active = within < s_region_fill[lo];
       idx = lo * region_entries + within;
@@ -522,6 +534,8 @@ bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict
     }
 
     bool alive = false;      // continues to the next bounce
+    bool emits = false;      // ended on an emitter: its spectrum is formed by emit_kernel
+    uint32_t emit_info = 0;
     V3 no = ro, nd = rd;
     if (active) {
       Hit hit;
@@ -547,7 +561,10 @@ bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict
           if (!PRIMARY && dot(hit.n, rd) > 0.0) hit.n = neg(hit.n);
           const uint32_t hit_index = b.max_depth - remaining;
           if (m.type == RT_MAT_EMITTER) {            // src/scene.rs:56-62
-            if (m.present & RT_HAS_EMITTED) { emit_sample(sc.spectra, m.emitted, chain, hit_index, xyz, spectrum_out); contributes = true; }
+            if (m.present & RT_HAS_EMITTED) {
+              if (o.emit_counts) { emits = true; emit_info = uint32_t(m.emitted) | (hit_index << 8); }
+              else { emit_sample(sc.spectra, m.emitted, chain, hit_index, xyz, spectrum_out); contributes = true; }
+            }
           } else if (m.type == RT_MAT_LAMBERTIAN) {  // src/scene.rs:63-79
             if ((m.present & RT_HAS_AMBIENT) && remaining > 1) {
               double r1, r2;
@@ -567,8 +584,34 @@ bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict
       }
       if (contributes) {
         o.contrib_x[slot] = xyz[0]; o.contrib_y[slot] = xyz[1]; o.contrib_z[slot] = xyz[2];
-      } else if (spectrum_out && !alive) {
+      } else if (spectrum_out && !alive && !emits) {
         for (int i = 0; i < RT_NBINS; ++i) spectrum_out[i] = 0.0f;
+      }
+    }
+
+    // emitter hits: same ballot-and-one-atomic append, into the emit queue. A wave that finds its
+    // region full marks what it reserved as unused and forms its spectra in place instead.
+    const unsigned long long emask = __ballot(emits);
+    if (emask) {
+      const uint32_t lane = __lane_id();
+      const uint32_t leader = uint32_t(__ffsll((long long)emask)) - 1u;
+      const uint32_t region = chunk % kShards, want = uint32_t(__popcll(emask));
+      uint32_t start = 0;
+      if (lane == leader) start = atomicAdd(o.emit_counts + region * kCountStride, want);
+      start = __shfl(start, int(leader));
+      const uint32_t rank = uint32_t(__popcll(emask & ((1ull << lane) - 1ull)));
+      const bool fits = start + want <= o.emit_region_entries;
+      if (emits) {
+        const uint32_t at = region * o.emit_region_entries + start + rank;
+        if (fits) {
+          o.emit.slot[at] = slot; o.emit.info[at] = emit_info; o.emit.chain0[at] = chain.a;
+          if (deep) o.emit.chain1[at] = chain.b;
+        } else {
+          if (start + rank < o.emit_region_entries) o.emit.slot[at] = RT_MISS;
+          float xyz[3];
+          emit_sample(sc.spectra, emit_info & 0xFFu, chain, emit_info >> 8, xyz, o.spectra ? o.spectra + size_t(slot) * RT_NBINS : nullptr);
+          o.contrib_x[slot] = xyz[0]; o.contrib_y[slot] = xyz[1]; o.contrib_z[slot] = xyz[2];
+        }
       }
     }
 
@@ -593,6 +636,28 @@ bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict
     unsigned long long a = n_nodes, c = n_prims;
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); c += __shfl_down(c, off); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&counters->nodes, a); atomicAdd(&counters->prims, c); }
+  }
+}
+
+// One thread per queued emitter hit: Le * (chain product) in the reference's order, then to_XYZ.
+__global__ void __launch_bounds__(kBlock) emit_kernel(DevScene sc, TraceOutputs o, bool deep) {
+  __shared__ uint32_t s_chunk_prefix[kShards + 1];
+  __shared__ uint32_t s_region_fill[kShards];
+  const uint32_t n_chunks = number_chunks(o.emit_counts, o.emit_region_entries, s_chunk_prefix, s_region_fill);
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t region = find_region(s_chunk_prefix, chunk);
+    const uint32_t within = (chunk - s_chunk_prefix[region]) * kBlock + threadIdx.x;
+    if (within >= s_region_fill[region]) continue;
+    const uint32_t at = region * o.emit_region_entries + within;
+    const uint32_t slot = o.emit.slot[at];
+    if (slot == RT_MISS) continue;
+    const uint32_t info = o.emit.info[at];
+    Chain chain;
+    chain.a = o.emit.chain0[at];
+    chain.b = deep ? o.emit.chain1[at] : make_uint4(0, 0, 0, 0);
+    float xyz[3];
+    emit_sample(sc.spectra, info & 0xFFu, chain, info >> 8, xyz, o.spectra ? o.spectra + size_t(slot) * RT_NBINS : nullptr);
+    o.contrib_x[slot] = xyz[0]; o.contrib_y[slot] = xyz[1]; o.contrib_z[slot] = xyz[2];
   }
 }
 
@@ -737,6 +802,11 @@ void launch_intersect(const DevScene& sc, const void* rays_, size_t n, void* hit
     case 6: hipLaunchKernelGGL((intersect_kernel<1, true, false>), grid, kBlock, lds, s, sc, rays, n, hits, counters); break;
     default: hipLaunchKernelGGL((intersect_kernel<1, true, true>), grid, kBlock, lds, s, sc, rays, n, hits, counters); break;
   }
+}
+
+void launch_emit(const DevScene& sc, TraceOutputs o, bool deep, uint32_t max_entries, hipStream_t s) {
+  if (!o.emit_counts || max_entries == 0) return;
+  hipLaunchKernelGGL(emit_kernel, dim3(grid_for(size_t(max_entries) + size_t(kShards) * kBlock)), kBlock, 0, s, sc, o, deep);
 }
 
 void launch_resolve(const BatchDesc& b, TraceOutputs o, float* xyz_sum, hipStream_t s) {

@@ -74,6 +74,11 @@ struct rtmi_ctx {
   size_t queue_paths = 0;
   bool queue_deep = false;
   DevBuf contrib, counts, tiles, stats, rays, hits, spectra_out, image;
+  DevBuf emit_mem;
+  EmitQueue emit{};
+  uint32_t emit_region_entries = 0;
+  size_t emit_paths = 0;
+  bool emit_deep = false;
 };
 
 struct rtmi_scene {
@@ -110,7 +115,7 @@ PathQueue carve_queue(void* base, size_t paths, bool deep) {
 
 size_t queue_bytes(size_t entries, bool deep) { return entries * (6 * 8 + 4 * 4 + 16 + (deep ? 16 : 0)) + 12 * 256; }
 constexpr size_t kCountLevelWords = size_t(kShards) * kCountStride;            // uint32 words per queue level
-constexpr size_t kCountBytes = (RT_MAX_DEPTH + 2) * kCountLevelWords * sizeof(uint32_t);
+constexpr size_t kCountBytes = (RT_MAX_DEPTH + 3) * kCountLevelWords * sizeof(uint32_t);  // queue levels + the emit queue
 
 int ensure_workspace(rtmi_ctx* ctx, size_t paths, bool deep, bool want_queues) {
   if (want_queues && (paths > ctx->queue_paths || (deep && !ctx->queue_deep))) {
@@ -122,6 +127,21 @@ int ensure_workspace(rtmi_ctx* ctx, size_t paths, bool deep, bool want_queues) {
       ctx->queue[i] = carve_queue(ctx->queue_mem[i].p, queue_entries(p), d);
     }
     ctx->queue_paths = p; ctx->queue_deep = d;
+  }
+  if (want_queues && (paths > ctx->emit_paths || (deep && !ctx->emit_deep))) {
+    // emit queue: kShards regions, each twice its fair share of the batch (a wave that finds its region full
+    // evaluates in place, so this is a performance knob, not a correctness bound)
+    const size_t p = std::max(paths, ctx->emit_paths);
+    const bool d = deep || ctx->emit_deep;
+    const uint32_t region = uint32_t(((2 * p / kShards + kBlock) + kBlock - 1) / kBlock * kBlock);
+    const size_t entries = size_t(region) * kShards;
+    ctx->emit_mem.release();
+    if (int rc = ctx->emit_mem.reserve(entries * (4 + 4 + 16 + (d ? 16 : 0)) + 4 * 256)) return rc;
+    char* base = ctx->emit_mem.as<char>();
+    auto take = [&](size_t bytes) { void* r = base; base += (bytes + 255) & ~size_t(255); return r; };
+    ctx->emit.slot = (uint32_t*)take(entries * 4); ctx->emit.info = (uint32_t*)take(entries * 4);
+    ctx->emit.chain0 = (uint4*)take(entries * 16); ctx->emit.chain1 = d ? (uint4*)take(entries * 16) : nullptr;
+    ctx->emit_region_entries = region; ctx->emit_paths = p; ctx->emit_deep = d;
   }
   if (int rc = ctx->contrib.reserve(paths * 3 * sizeof(float))) return rc;
   if (int rc = ctx->counts.reserve(kCountBytes)) return rc;
@@ -198,12 +218,17 @@ int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra
   rtmi_ctx* ctx = sc->ctx;
   uint32_t* counts = ctx->counts.as<uint32_t>();
   float* contrib = ctx->contrib.as<float>();
-  TraceOutputs o{contrib, contrib + n_paths, contrib + 2 * n_paths, spectra_out};
+  TraceOutputs o{contrib, contrib + n_paths, contrib + 2 * n_paths, spectra_out, EmitQueue{}, nullptr, 0};
   DeviceStats* ds = ctx->stats.as<DeviceStats>();
   TraversalCounters* counters = sc->counting ? &ds->trav : nullptr;
   const uint32_t depth = b.integrator == RT_INT_RANDOM_WALK ? b.max_depth : 0;
-  // queue level k holds the paths that enter bounce k; its kShards fill counters sit at counts + k * kCountLevelWords
-  HIP_TRY(hipMemsetAsync(counts, 0, (size_t(depth) + 2) * kCountLevelWords * sizeof(uint32_t), stream));
+  // queue level k holds the paths that enter bounce k; its kShards fill counters sit at counts + k * kCountLevelWords;
+  // the emit queue's counters follow the last level
+  HIP_TRY(hipMemsetAsync(counts, 0, (size_t(depth) + 3) * kCountLevelWords * sizeof(uint32_t), stream));
+  const bool deep = depth > 16;
+  if (depth >= 1 && ctx->emit_paths >= n_paths && (!deep || ctx->emit_deep) && !getenv("RTMI_INLINE_EMIT")) {
+    o.emit = ctx->emit; o.emit_counts = counts + (size_t(depth) + 2) * kCountLevelWords; o.emit_region_entries = ctx->emit_region_entries;
+  }
   HIP_TRY(hipMemsetAsync(contrib, 0, n_paths * 3 * sizeof(float), stream));
   const uint32_t region_entries = region_chunks(ctx->queue_paths) * kBlock;
   clock.begin();
@@ -217,6 +242,7 @@ int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra
     clock.end();
     ++launches;
   }
+  launch_emit(sc->dev, o, deep, uint32_t(n_paths), stream);
   if (depth > 1) launch_sum_counts(counts + kCountLevelWords, depth - 1, &ds->bounce_segments, stream);
   HIP_TRY(hipGetLastError());
   return RTMI_OK;
@@ -260,7 +286,7 @@ extern "C" void rtmi_ctx_destroy(rtmi_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   for (auto& q : ctx->queue_mem) q.release();
-  for (DevBuf* b : {&ctx->contrib, &ctx->counts, &ctx->tiles, &ctx->stats, &ctx->rays, &ctx->hits, &ctx->spectra_out, &ctx->image})
+  for (DevBuf* b : {&ctx->contrib, &ctx->counts, &ctx->tiles, &ctx->stats, &ctx->rays, &ctx->hits, &ctx->spectra_out, &ctx->image, &ctx->emit_mem})
     b->release();
   delete ctx;
 }
@@ -597,7 +623,7 @@ extern "C" int rtmi_render_accumulate(rtmi_scene* s, const rtmi_camera* cam, con
       const size_t n_paths = size_t(b.n_local_pixels) * b.n_samples;
       if (int rc = run_batch(s, b, n_paths, nullptr, stream, clock, launches)) return rc;
       float* contrib = ctx->contrib.as<float>();
-      launch_resolve(b, TraceOutputs{contrib, contrib + n_paths, contrib + 2 * n_paths, nullptr}, dev_xyz_sum, stream);
+      launch_resolve(b, TraceOutputs{contrib, contrib + n_paths, contrib + 2 * n_paths, nullptr, EmitQueue{}, nullptr, 0}, dev_xyz_sum, stream);
       HIP_TRY(hipGetLastError());
       if (clock.on) kernel_ms += clock.drain();
       ++batches;
