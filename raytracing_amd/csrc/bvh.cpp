@@ -39,13 +39,15 @@ struct Builder {
   BvhBuild out;
   uint32_t leaf_size;
   double pad;
+  double center[3];
 
-  // binary32 box that contains the binary64 one: pad, then round outward
+  // binary32 box, relative to the mesh centre, that contains the binary64 one: pad, then round outward
   void store_box(const Box& b, float* lo, float* hi) const {
     for (int k = 0; k < 3; ++k) {
-      float l = float(b.lo[k] - pad), h = float(b.hi[k] + pad);
-      if (double(l) > b.lo[k] - pad) l = std::nextafterf(l, -FLT_MAX);
-      if (double(h) < b.hi[k] + pad) h = std::nextafterf(h, FLT_MAX);
+      const double dl = (b.lo[k] - center[k]) - pad, dh = (b.hi[k] - center[k]) + pad;
+      float l = float(dl), h = float(dh);
+      if (double(l) > dl) l = std::nextafterf(l, -FLT_MAX);
+      if (double(h) < dh) h = std::nextafterf(h, FLT_MAX);
       lo[k] = l; hi[k] = h;
     }
   }
@@ -154,8 +156,15 @@ BvhBuild build_bvh(const double* tri_vertices, uint32_t n, uint32_t leaf_size) {
     for (int k = 0; k < 3; ++k) p.c[k] = 0.5 * (p.box.lo[k] + p.box.hi[k]);
     all.grow(p.box);
   }
-  double extent = 0.0;
-  if (n) for (int k = 0; k < 3; ++k) extent = std::max(extent, std::max(std::fabs(all.lo[k]), std::fabs(all.hi[k])));
+  double extent = 0.0, r2 = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    bld.center[k] = n ? 0.5 * (all.lo[k] + all.hi[k]) : 0.0;
+    const double half = n ? 0.5 * (all.hi[k] - all.lo[k]) : 0.0;
+    extent = std::max(extent, half);
+    r2 += half * half;
+    bld.out.center[k] = bld.center[k];
+  }
+  bld.out.radius = std::sqrt(r2) * (1.0 + 0x1.0p-20);
   bld.pad = extent * 0x1.0p-20 + 1e-30;
   bld.out.nodes.reserve(n ? 2 * size_t(n) / bld.leaf_size + 2 : 1);
   bld.out.tris.reserve(n);

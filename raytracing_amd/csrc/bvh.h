@@ -11,13 +11,16 @@ struct BvhBuild {
   std::vector<BvhNode> nodes;        // nodes[0] is the root; child refs are relative to it
   std::vector<DevMeshTri> tris;      // leaf order; .index = position in the input array
   uint32_t max_depth = 0;            // deepest chain of inner nodes (bounds the traversal stack)
+  double center[3] = {0, 0, 0};      // node boxes are stored relative to this point ...
+  double radius = 0;                 // ... and every triangle lies within this distance of it
 };
 
 // Binned-SAH build over `n` triangles given as 9 doubles each (world space, file order).
 // The reference has no acceleration structure (src/shapes/model_obj.rs:77-87 scans every
 // triangle); the tree only prunes work, it never changes which triangle wins under either
-// hit rule. Boxes are stored in binary32 rounded outward and padded, so a box test done in
-// binary64 against them can never reject a triangle the exact test would accept.
+// hit rule. Boxes are stored in binary32, relative to the mesh centre, rounded outward and
+// padded; together with the per-ray margin the kernel adds, a binary32 box test against them can
+// never reject a triangle the exact binary64 test would accept.
 BvhBuild build_bvh(const double* tri_vertices, uint32_t n, uint32_t leaf_size);
 
 }  // namespace rtmi

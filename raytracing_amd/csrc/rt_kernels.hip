@@ -147,17 +147,72 @@ __device__ __forceinline__ bool sphere_t(const DevSphere& s, V3 o, V3 d, double&
   return true;
 }
 
-// Box test in binary64 against a binary32 box that was rounded outward and padded at build
-// time. NaNs from 0 * inf drop out of fmin/fmax, which only makes the test more permissive.
-__device__ __forceinline__ bool slab(const float* lo, const float* hi, V3 invd, V3 oid, double tmax, double& tnear) {
-  const double ax = fma(double(lo[0]), invd.x, -oid.x), bx = fma(double(hi[0]), invd.x, -oid.x);
-  const double ay = fma(double(lo[1]), invd.y, -oid.y), by = fma(double(hi[1]), invd.y, -oid.y);
-  const double az = fma(double(lo[2]), invd.z, -oid.z), bz = fma(double(hi[2]), invd.z, -oid.z);
-  const double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmax(fmin(az, bz), 0.0));
-  const double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmin(fmax(az, bz), tmax));
-  tnear = tn;
-  return tn <= tf;
+// The ray as the binary32 tests see it: origin relative to the mesh centre, direction and its
+// reciprocal, and delta, a bound on how far the binary32 ray can stray from the binary64 one
+// anywhere inside the mesh (rounding of the origin, 2^-24 |o - c|, plus rounding of the direction
+// over the longest useful distance, 2^-24 (|o - c| + R)). Growing every box by delta keeps the box
+// test conservative; 2^-21 (|o - c| + R) leaves a factor of four to spare.
+struct BoxRay { float ox, oy, oz, dx, dy, dz, ix, iy, iz, delta; };
+
+__device__ __forceinline__ BoxRay make_box_ray(V3 o, V3 d, const DevObject& ob) {
+  BoxRay r;
+  r.ox = float(o.x - ob.center[0]); r.oy = float(o.y - ob.center[1]); r.oz = float(o.z - ob.center[2]);
+  r.delta = 0x1.0p-21f * (fmaxf(fmaxf(fabsf(r.ox), fabsf(r.oy)), fabsf(r.oz)) + float(ob.radius) * 1.0000005f);
+  r.dx = float(d.x); r.dy = float(d.y); r.dz = float(d.z);
+  r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+  return r;
 }
+
+// Slab test in binary32 against a box grown by the ray's delta. A zero direction component gives
+// +-inf or NaN; fminf/fmaxf drop a NaN operand, which only makes the test more permissive. The
+// final comparison allows for the rounding of the six subtract-multiply pairs.
+__device__ __forceinline__ bool slab32(const float* lo, const float* hi, const BoxRay& r, float tmax, float& tnear) {
+  const float ax = (lo[0] - (r.ox + r.delta)) * r.ix, bx = (hi[0] - (r.ox - r.delta)) * r.ix;
+  const float ay = (lo[1] - (r.oy + r.delta)) * r.iy, by = (hi[1] - (r.oy - r.delta)) * r.iy;
+  const float az = (lo[2] - (r.oz + r.delta)) * r.iz, bz = (hi[2] - (r.oz - r.delta)) * r.iz;
+  const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+  const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+  tnear = tn;
+  return tn <= tf * 1.000002f;
+}
+
+// Cheap binary32 screen in front of the exact triangle test: returns false only when the exact
+// binary64 Moller-Trumbore is certain to reject. The same determinants are formed in binary32
+// (fused multiply-adds are fine here) and compared against bounds on their own error:
+//   rounding of U = p.tv, V = q.d      <= 21 * 2^-24 * s * D   (s = largest edge component, D = largest |tv| component)
+//   displacement of the ray by delta   <= 6 * s * delta
+//   rounding of det = p.e1             <= 15 * 2^-24 * s^2
+// The tolerances below (2^-18 s D + 8 s delta, 2^-18 s^2) carry a factor of three or more on top.
+__device__ __forceinline__ bool triangle_maybe_hit(const DevTriFilter& f, const BoxRay& r, float tmax) {
+  const float tx = r.ox - f.v0[0], ty = r.oy - f.v0[1], tz = r.oz - f.v0[2];
+  const float px = __builtin_fmaf(r.dy, f.e2[2], -(r.dz * f.e2[1]));
+  const float py = __builtin_fmaf(r.dz, f.e2[0], -(r.dx * f.e2[2]));
+  const float pz = __builtin_fmaf(r.dx, f.e2[1], -(r.dy * f.e2[0]));
+  const float qx = __builtin_fmaf(ty, f.e1[2], -(tz * f.e1[1]));
+  const float qy = __builtin_fmaf(tz, f.e1[0], -(tx * f.e1[2]));
+  const float qz = __builtin_fmaf(tx, f.e1[1], -(ty * f.e1[0]));
+  const float det = __builtin_fmaf(px, f.e1[0], __builtin_fmaf(py, f.e1[1], pz * f.e1[2]));
+  const float big_d = fmaxf(fmaxf(fabsf(tx), fabsf(ty)), fabsf(tz));
+  const float tol = f.scale * __builtin_fmaf(0x1.0p-18f, big_d, 8.0f * r.delta);
+  const float tol_det = 0x1.0p-18f * f.scale * f.scale;
+  const float ad = fabsf(det);
+  if (ad <= 4.0f * tol_det) return true;  // edge-on or tiny: let the exact test decide
+  const float u = copysignf(1.0f, det) * __builtin_fmaf(px, tx, __builtin_fmaf(py, ty, pz * tz));
+  const float v = copysignf(1.0f, det) * __builtin_fmaf(qx, r.dx, __builtin_fmaf(qy, r.dy, qz * r.dz));
+  const float t = copysignf(1.0f, det) * __builtin_fmaf(qx, f.e2[0], __builtin_fmaf(qy, f.e2[1], qz * f.e2[2]));
+  if (u < -tol || v < -tol || u + v > ad + 2.0f * tol + tol_det) return false;
+  const float tol_t = tol * f.scale;
+  if (t < -tol_t) return false;
+  if (t - tol_t > tmax * (ad + tol_det) * 1.00001f) return false;  // nearest rule only: tmax is +inf otherwise
+  return true;
+}
+
+// Experiment knob: ask the register allocator for a given number of waves per SIMD.
+#ifdef RT_EXP_WAVES
+#define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RT_EXP_WAVES, RT_EXP_WAVES)))
+#else
+#define RT_WAVES_ATTR
+#endif
 
 struct MeshHit { double t, t_raw; uint32_t index; uint32_t slot; };
 
@@ -166,65 +221,73 @@ struct MeshHit { double t, t_raw; uint32_t index; uint32_t slot; };
 // src/shapes/model_obj.rs:80-84): subtrees whose smallest index cannot beat the current
 // winner are skipped, distance never prunes. RULE = RT_HIT_NEAREST returns the smallest t,
 // ties to the smaller index. The traversal stack lives in LDS, one column per lane.
+//
+// Two nested loops: lanes first walk inner nodes (cheap binary32 box tests) until each holds a
+// leaf or is done, then the wave does its leaves together, so the expensive triangle code runs
+// once per leaf a lane visits instead of once per node step of the slowest lane. Triangles go
+// through the binary32 screen first; only survivors load the binary64 vertices for the exact test.
 template <int RULE, bool COUNT>
 __device__ __forceinline__ bool mesh_closest(const uint4* __restrict__ nodes, const DevMeshTri* __restrict__ tris,
-                                             V3 o, V3 d, uint32_t* stack, MeshHit& best, uint32_t& n_nodes,
-                                             uint32_t& n_prims) {
-  const V3 invd = mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-  const V3 oid = mk(o.x * invd.x, o.y * invd.y, o.z * invd.z);
+                                             const DevTriFilter* __restrict__ filters, const DevObject& ob, V3 o, V3 d,
+                                             uint32_t* stack, MeshHit& best, uint32_t& n_nodes, uint32_t& n_prims) {
+  const BoxRay br = make_box_ray(o, d, ob);
   best.t = INFINITY; best.t_raw = 0.0; best.index = RT_MISS; best.slot = 0;
+  constexpr uint32_t kDone = RT_REF_NONE;  // has the leaf bit set, so it also ends the node loop
   uint32_t cur = 0;
   int sp = 0;
   for (;;) {
-    if (cur & RT_LEAF_FLAG) {
-      const uint32_t first = (cur & ~RT_LEAF_FLAG) >> 4, cnt = cur & 15u;
-      for (uint32_t i = 0; i < cnt; ++i) {
-        const DevMeshTri* tp = tris + first + i;
-        const uint32_t index = tp->index;
-        if (RULE == RT_HIT_FIRST_INDEX && index >= best.index) break;  // leaf is sorted by index
-        const double2* q = reinterpret_cast<const double2*>(tp->v);
-        const double2 a = q[0], b = q[1], c = q[2], e = q[3];
-        const double last = tp->v[8];
-        if (COUNT) ++n_prims;
-        double t_raw, t;
-        if (triangle_hit(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), mk(e.x, e.y, last), o, d, t_raw, t)) {
-          if (RULE == RT_HIT_FIRST_INDEX) {
-            best.t = t; best.t_raw = t_raw; best.index = index; best.slot = first + i;
-            break;
-          } else if (t < best.t || (t == best.t && index < best.index)) {
-            best.t = t; best.t_raw = t_raw; best.index = index; best.slot = first + i;
-          }
+    while (!(cur & RT_LEAF_FLAG)) {
+      const uint4* np = nodes + size_t(cur) * 4;   // 64-byte node = 4 x 16 bytes, from LDS when the tree is staged
+      const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+      if (COUNT) ++n_nodes;
+      const float lo0[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
+      const float hi0[3] = {__uint_as_float(w0.w), __uint_as_float(w1.x), __uint_as_float(w1.y)};
+      const float lo1[3] = {__uint_as_float(w1.z), __uint_as_float(w1.w), __uint_as_float(w2.x)};
+      const float hi1[3] = {__uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w)};
+      const uint32_t ref0 = w3.x, ref1 = w3.y, min0 = w3.z, min1 = w3.w;
+      // nearest rule: nothing farther than the best hit so far (rounded up, with the same slack) can win
+      const float tmax = RULE == RT_HIT_NEAREST ? __double2float_ru(best.t) * 1.000002f : INFINITY;
+      float tn0, tn1;
+      bool h0 = ref0 != RT_REF_NONE && slab32(lo0, hi0, br, tmax, tn0);
+      bool h1 = ref1 != RT_REF_NONE && slab32(lo1, hi1, br, tmax, tn1);
+      if (RULE == RT_HIT_FIRST_INDEX) { h0 = h0 && min0 < best.index; h1 = h1 && min1 < best.index; }
+      if (h0 && h1) {
+        const bool swap = RULE == RT_HIT_FIRST_INDEX ? (min1 < min0) : (tn1 < tn0);
+        stack[(sp++) * kBlock] = swap ? ref0 : ref1;
+        cur = swap ? ref1 : ref0;
+      } else if (h0) {
+        cur = ref0;
+      } else if (h1) {
+        cur = ref1;
+      } else {
+        cur = sp ? stack[(--sp) * kBlock] : kDone;
+      }
+    }
+    if (cur == kDone) break;
+    const uint32_t first = (cur & ~RT_LEAF_FLAG) >> 4, cnt = cur & 15u;
+    for (uint32_t i = 0; i < cnt; ++i) {
+      const DevTriFilter f = filters[first + i];
+      if (RULE == RT_HIT_FIRST_INDEX && f.index >= best.index) break;  // a leaf is sorted by index
+      if (COUNT) ++n_prims;
+      const float tmax = RULE == RT_HIT_NEAREST ? __double2float_ru(best.t) * 1.000002f : INFINITY;
+#ifndef RT_EXP_NO_TRI_FILTER
+      if (!triangle_maybe_hit(f, br, tmax)) continue;
+#endif
+      const DevMeshTri* tp = tris + first + i;
+      const double2* q = reinterpret_cast<const double2*>(tp->v);
+      const double2 a = q[0], b = q[1], c = q[2], e = q[3];
+      const double last = tp->v[8];
+      double t_raw, t;
+      if (triangle_hit(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), mk(e.x, e.y, last), o, d, t_raw, t)) {
+        if (RULE == RT_HIT_FIRST_INDEX) {
+          best.t = t; best.t_raw = t_raw; best.index = f.index; best.slot = first + i;
+          break;
+        } else if (t < best.t || (t == best.t && f.index < best.index)) {
+          best.t = t; best.t_raw = t_raw; best.index = f.index; best.slot = first + i;
         }
       }
-      if (sp == 0) break;
-      cur = stack[(--sp) * kBlock];
-      continue;
     }
-    const uint4* np = nodes + size_t(cur) * 4;   // 64-byte node = 4 x 16 bytes, from LDS when the tree is staged
-    const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-    if (COUNT) ++n_nodes;
-    const float lo0[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
-    const float hi0[3] = {__uint_as_float(w0.w), __uint_as_float(w1.x), __uint_as_float(w1.y)};
-    const float lo1[3] = {__uint_as_float(w1.z), __uint_as_float(w1.w), __uint_as_float(w2.x)};
-    const float hi1[3] = {__uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w)};
-    const uint32_t ref0 = w3.x, ref1 = w3.y, min0 = w3.z, min1 = w3.w;
-    const double tmax = RULE == RT_HIT_NEAREST ? best.t : INFINITY;
-    double tn0, tn1;
-    bool h0 = ref0 != RT_REF_NONE && slab(lo0, hi0, invd, oid, tmax, tn0);
-    bool h1 = ref1 != RT_REF_NONE && slab(lo1, hi1, invd, oid, tmax, tn1);
-    if (RULE == RT_HIT_FIRST_INDEX) { h0 = h0 && min0 < best.index; h1 = h1 && min1 < best.index; }
-    if (h0 && h1) {
-      const bool swap = RULE == RT_HIT_FIRST_INDEX ? (min1 < min0) : (tn1 < tn0);
-      stack[(sp++) * kBlock] = swap ? ref0 : ref1;
-      cur = swap ? ref1 : ref0;
-    } else if (h0) {
-      cur = ref0;
-    } else if (h1) {
-      cur = ref1;
-    } else {
-      if (sp == 0) break;
-      cur = stack[(--sp) * kBlock];
-    }
+    cur = sp ? stack[(--sp) * kBlock] : kDone;
   }
   return best.index != RT_MISS;
 }
@@ -257,7 +320,8 @@ __device__ __forceinline__ bool closest_hit(const DevScene& sc, const uint4* __r
       ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, t_raw, t);
     } else {
       MeshHit mh;
-      ok = mesh_closest<RULE, COUNT>(node_words + size_t(ob.root) * 4, sc.mesh_tris + ob.first, o, dn, stack, mh, n_nodes, n_prims);
+      ok = mesh_closest<RULE, COUNT>(node_words + size_t(ob.root) * 4, sc.mesh_tris + ob.first, sc.mesh_filters + ob.first, ob,
+                                     o, dn, stack, mh, n_nodes, n_prims);
       t = mh.t; t_raw = mh.t_raw; prim = mh.index; slot = mh.slot;
     }
     if (ok && (!found || t < best_t)) {
@@ -464,7 +528,7 @@ __device__ __forceinline__ uint32_t find_region(const uint32_t* s_prefix, uint32
 //   emitter                                 : the path ends, contributing Le * (chain product)
 //   Lambertian / specular                   : the path continues into `out`
 template <bool PRIMARY, int RULE, bool COUNT, bool STAGED>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) RT_WAVES_ATTR
 bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_counts, uint32_t region_entries,
               PathQueue out, uint32_t* __restrict__ out_counts, TraceOutputs o, TraversalCounters* counters) {
   extern __shared__ uint4 lds_dynamic[];
@@ -666,7 +730,7 @@ struct HitOut { uint32_t obj, prim; double t; double p[3]; double n[3]; };
 static_assert(sizeof(HitOut) == 64, "hit record must be 64 bytes");
 
 template <int RULE, bool COUNT, bool STAGED>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) RT_WAVES_ATTR
 intersect_kernel(DevScene sc, const double* __restrict__ rays, size_t n, HitOut* __restrict__ hits, TraversalCounters* counters) {
   extern __shared__ uint4 lds_dynamic[];
   uint32_t* stack;
