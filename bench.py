@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--rule", default="first_index", choices=["first_index", "nearest"])
     ap.add_argument("--partition", default="samples", choices=["samples", "tiles"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-paths", type=int, default=0, help="path slots per batch of launches (0 = library default)")
     ap.add_argument("--cpu-spp", type=int, default=0, help="samples per pixel of the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
 
@@ -83,7 +84,7 @@ def main():
 
     w = WORKLOADS[args.workload]
     hit_rule = L.HIT_FIRST_INDEX if args.rule == "first_index" else L.HIT_NEAREST
-    ctx = api.Context(local_rank)
+    ctx = api.Context(local_rank, args.batch_paths)
     scene, cam = build_scene(ctx, w, hit_rule)
     width, height, spp, depth = cam.width, cam.height, w["spp"], w["depth"]
     spp_job = spp * world if args.partition == "samples" else spp     # weak scaling in samples

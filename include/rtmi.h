@@ -139,7 +139,8 @@ typedef struct rtmi_scene rtmi_scene;
 
 /* Binds a context to GPU `device_id` (-1 = the current HIP device). Replaces nothing in the
  * reference: the reference has no device. max_batch_paths caps the path slots (and so the
- * memory) one render batch uses; 0 = default. */
+ * memory) one render batch uses; 0 = default, 2^27 slots (about 230 bytes of workspace per slot,
+ * allocated only up to what a render actually needs). */
 int rtmi_ctx_create(int device_id, uint64_t max_batch_paths, rtmi_ctx** out);
 void rtmi_ctx_destroy(rtmi_ctx* ctx);
 /* Message of the calling thread's most recent failed call ("" if none). */

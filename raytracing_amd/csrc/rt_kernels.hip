@@ -176,6 +176,7 @@ __device__ __forceinline__ bool slab32(const float* lo, const float* hi, const B
   return tn <= tf * 1.000002f;
 }
 
+#ifdef RT_TRI_FILTER
 // Cheap binary32 screen in front of the exact triangle test: returns false only when the exact
 // binary64 Moller-Trumbore is certain to reject. The same determinants are formed in binary32
 // (fused multiply-adds are fine here) and compared against bounds on their own error:
@@ -206,6 +207,7 @@ __device__ __forceinline__ bool triangle_maybe_hit(const DevTriFilter& f, const 
   if (t - tol_t > tmax * (ad + tol_det) * 1.00001f) return false;  // nearest rule only: tmax is +inf otherwise
   return true;
 }
+#endif
 
 // Experiment knob: ask the register allocator for a given number of waves per SIMD.
 #ifdef RT_EXP_WAVES
@@ -224,8 +226,10 @@ struct MeshHit { double t, t_raw; uint32_t index; uint32_t slot; };
 //
 // Two nested loops: lanes first walk inner nodes (cheap binary32 box tests) until each holds a
 // leaf or is done, then the wave does its leaves together, so the expensive triangle code runs
-// once per leaf a lane visits instead of once per node step of the slowest lane. Triangles go
-// through the binary32 screen first; only survivors load the binary64 vertices for the exact test.
+// once per leaf a lane visits instead of once per node step of the slowest lane. Built with
+// -DRT_TRI_FILTER, triangles go through a binary32 screen first and only survivors take the exact
+// binary64 test; on the scenes measured so far the extra registers cost more than the screen saves,
+// so it is off by default.
 template <int RULE, bool COUNT>
 __device__ __forceinline__ bool mesh_closest(const uint4* __restrict__ nodes, const DevMeshTri* __restrict__ tris,
                                              const DevTriFilter* __restrict__ filters, const DevObject& ob, V3 o, V3 d,
@@ -266,24 +270,29 @@ __device__ __forceinline__ bool mesh_closest(const uint4* __restrict__ nodes, co
     if (cur == kDone) break;
     const uint32_t first = (cur & ~RT_LEAF_FLAG) >> 4, cnt = cur & 15u;
     for (uint32_t i = 0; i < cnt; ++i) {
+      const DevMeshTri* tp = tris + first + i;
+#ifdef RT_TRI_FILTER
       const DevTriFilter f = filters[first + i];
-      if (RULE == RT_HIT_FIRST_INDEX && f.index >= best.index) break;  // a leaf is sorted by index
+      const uint32_t index = f.index;
+#else
+      const uint32_t index = tp->index;
+#endif
+      if (RULE == RT_HIT_FIRST_INDEX && index >= best.index) break;  // a leaf is sorted by index
       if (COUNT) ++n_prims;
+#ifdef RT_TRI_FILTER
       const float tmax = RULE == RT_HIT_NEAREST ? __double2float_ru(best.t) * 1.000002f : INFINITY;
-#ifndef RT_EXP_NO_TRI_FILTER
       if (!triangle_maybe_hit(f, br, tmax)) continue;
 #endif
-      const DevMeshTri* tp = tris + first + i;
       const double2* q = reinterpret_cast<const double2*>(tp->v);
       const double2 a = q[0], b = q[1], c = q[2], e = q[3];
       const double last = tp->v[8];
       double t_raw, t;
       if (triangle_hit(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), mk(e.x, e.y, last), o, d, t_raw, t)) {
         if (RULE == RT_HIT_FIRST_INDEX) {
-          best.t = t; best.t_raw = t_raw; best.index = f.index; best.slot = first + i;
+          best.t = t; best.t_raw = t_raw; best.index = index; best.slot = first + i;
           break;
-        } else if (t < best.t || (t == best.t && f.index < best.index)) {
-          best.t = t; best.t_raw = t_raw; best.index = f.index; best.slot = first + i;
+        } else if (t < best.t || (t == best.t && index < best.index)) {
+          best.t = t; best.t_raw = t_raw; best.index = index; best.slot = first + i;
         }
       }
     }
@@ -297,6 +306,23 @@ struct Hit {
   double t;
   V3 p, n;
 };
+
+// Hit point and normal of the winning object only.
+__device__ __forceinline__ void hit_geometry(const DevScene& sc, const DevObject& ob, V3 o, V3 d, V3 dn, double t, double t_raw,
+                                             uint32_t tri_slot, V3& p, V3& n) {
+  if (ob.kind == RT_OBJ_SPHERE) {
+    const DevSphere& s = sc.spheres[ob.first];
+    const V3 lo = xf_pt(s.w2l, o), ld = normalize(xf_vec(s.w2l, d));
+    const V3 pl = lo + ld * t;
+    p = xf_pt(s.l2w, pl);                        // src/shapes/sphere.rs:98
+    n = normalize(xf_vec_t(s.w2l, pl));          // src/shapes/sphere.rs:37-43
+  } else {
+    const double* v = ob.kind == RT_OBJ_TRIANGLE ? sc.top_tris[ob.first].v : sc.mesh_tris[ob.first + tri_slot].v;
+    const V3 v0 = ld3(v), v1 = ld3(v + 3), v2 = ld3(v + 6);
+    p = o + dn * t_raw;                                          // src/shapes/triangle.rs:78-81
+    n = normalize(normalize(cross(v1 - v0, v2 - v0)));          // src/shapes/triangle.rs:30, then :91
+  }
+}
 
 // Scene::intersect_ray (src/scene.rs:135-150): closest over the object list in scene order,
 // strict '<' so the earlier object keeps a tie. The hit point and normal are formed once,
@@ -329,21 +355,37 @@ __device__ __forceinline__ bool closest_hit(const DevScene& sc, const uint4* __r
     }
   }
   if (!found) return false;
-  const DevObject ob = sc.objects[best_obj];
   hit.obj = best_obj; hit.prim = best_prim; hit.t = best_t;
-  if (ob.kind == RT_OBJ_SPHERE) {
-    const DevSphere& s = sc.spheres[ob.first];
-    const V3 lo = xf_pt(s.w2l, o), ld = normalize(xf_vec(s.w2l, d));
-    const V3 pl = lo + ld * best_t;
-    hit.p = xf_pt(s.l2w, pl);                        // src/shapes/sphere.rs:98
-    hit.n = normalize(xf_vec_t(s.w2l, pl));          // src/shapes/sphere.rs:37-43
-  } else {
-    const double* v = ob.kind == RT_OBJ_TRIANGLE ? sc.top_tris[ob.first].v : sc.mesh_tris[ob.first + best_slot].v;
-    const V3 v0 = ld3(v), v1 = ld3(v + 3), v2 = ld3(v + 6);
-    hit.p = o + dn * best_raw;                                       // src/shapes/triangle.rs:78-81
-    hit.n = normalize(normalize(cross(v1 - v0, v2 - v0)));          // src/shapes/triangle.rs:30, then :91
-  }
+  hit_geometry(sc, sc.objects[best_obj], o, d, dn, best_t, best_raw, best_slot, hit.p, hit.n);
   return true;
+}
+
+// The same loop restricted to spheres and lone triangles; of a mesh only the bounding box is
+// tested (conservatively, in binary32). Returns whether the ray meets any mesh's box, i.e. whether
+// traverse_kernel still has to look at this ray.
+struct Prelim { double t, t_raw; uint32_t obj; };
+
+__device__ __forceinline__ bool simple_objects(const DevScene& sc, V3 o, V3 d, V3 dn, Prelim& best) {
+  best.t = 0.0; best.t_raw = 0.0; best.obj = RT_MISS;
+  bool meets_mesh = false;
+  for (uint32_t i = 0; i < sc.n_objects; ++i) {
+    const DevObject ob = sc.objects[i];
+    double t, t_raw = 0.0;
+    bool ok;
+    if (ob.kind == RT_OBJ_SPHERE) {
+      ok = sphere_t(sc.spheres[ob.first], o, d, t);
+    } else if (ob.kind == RT_OBJ_TRIANGLE) {
+      const DevTopTri& tr = sc.top_tris[ob.first];
+      ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, t_raw, t);
+    } else {
+      const BoxRay br = make_box_ray(o, dn, ob);
+      float tn;
+      meets_mesh = meets_mesh || slab32(ob.box_lo, ob.box_hi, br, INFINITY, tn);
+      continue;
+    }
+    if (ok && (best.obj == RT_MISS || t < best.t)) { best.t = t; best.t_raw = t_raw; best.obj = i; }
+  }
+  return meets_mesh;
 }
 
 // ------------------------------------------------------------------------------- spectra
@@ -520,13 +562,176 @@ __device__ __forceinline__ uint32_t find_region(const uint32_t* s_prefix, uint32
   return lo;
 }
 
-// ------------------------------------------------------------------------------- the bounce kernel
+// ------------------------------------------------------------------------------- pieces of a bounce
 
-// One bounce for every path of a queue. PRIMARY: the path starts here (camera ray from the
-// Philox jitter, or a caller ray); otherwise its state comes from `in`.
+// What one path brings into a bounce.
+struct PathState {
+  V3 o, d;
+  uint32_t pixel, sample, slot, remaining;
+  Chain chain;
+};
+
+// Path `idx` of a batch at its start: the camera ray through its jittered pixel position
+// (evaluate_pixel_sample, src/integrators/integrator.rs:130-135 + Camera::get_ray, src/camera.rs:80-84),
+// or the caller's ray. Returns false for a pixel that the last tiles hang over the image edge.
+__device__ __forceinline__ bool start_path(const BatchDesc& b, uint32_t idx, PathState& s) {
+  s.slot = idx;
+  s.remaining = b.integrator == RT_INT_RANDOM_WALK ? b.max_depth : 0;
+  s.chain.a = make_uint4(0, 0, 0, 0); s.chain.b = make_uint4(0, 0, 0, 0);
+  if (b.rays) {
+    s.o = ld3(b.rays + size_t(idx) * 6); s.d = ld3(b.rays + size_t(idx) * 6 + 3);
+    s.pixel = b.pixel_base + idx; s.sample = b.sample0;
+    return true;
+  }
+  const uint32_t lp = idx % b.n_local_pixels;
+  s.sample = b.sample0 + idx / b.n_local_pixels;
+  uint32_t x, y;
+  if (!local_pixel_to_xy(b, lp, x, y)) return false;
+  s.pixel = y * b.cam.width + x;
+  double u0, u1;
+  uniform_pair(b.seed, s.pixel, s.sample, 0, 0, u0, u1);
+  const double fi = double(x) + u0 - 0.5, fj = double(y) + u1 - 0.5;
+  const V3 p1 = ld3(b.cam.p1), p2 = ld3(b.cam.p2), p3 = ld3(b.cam.p3), f = ld3(b.cam.focus);
+  const V3 right = ((p2 - p1) * fi) / double(b.cam.width);
+  const V3 down = ((p3 - p1) * fj) / double(b.cam.height);
+  s.o = f;
+  s.d = normalize(((p1 + right) + down) - f);
+  return true;
+}
+
+__device__ __forceinline__ void load_path(const PathQueue& q, uint32_t idx, bool deep, PathState& s) {
+  s.o = mk(q.ox[idx], q.oy[idx], q.oz[idx]);
+  s.d = mk(q.dx[idx], q.dy[idx], q.dz[idx]);
+  s.pixel = q.pixel[idx]; s.sample = q.sample[idx]; s.slot = q.slot[idx]; s.remaining = q.remaining[idx];
+  s.chain.a = q.chain0[idx];
+  s.chain.b = deep ? q.chain1[idx] : make_uint4(0, 0, 0, 0);
+}
+
+// What shading a hit decides.
 //   miss / black material / depth exhausted : the path ends, contributing nothing
 //   emitter                                 : the path ends, contributing Le * (chain product)
-//   Lambertian / specular                   : the path continues into `out`
+//   Lambertian / specular                   : the path continues along (no, nd)
+struct Shaded {
+  bool alive;       // continues to the next bounce
+  bool emits;       // ended on an emitter whose spectrum emit_kernel will form
+  uint32_t emit_info;
+  V3 no, nd;
+};
+
+// first_hit: the path's first intersection keeps its normal as is (src/integrators/random_walk.rs:74);
+// later hits turn it against the ray (src/scene.rs:30-32).
+__device__ __forceinline__ Shaded shade_hit(const DevScene& sc, const BatchDesc& b, const TraceOutputs& o, bool found, Hit& hit,
+                                            bool first_hit, PathState& s) {
+  Shaded r;
+  r.alive = false; r.emits = false; r.emit_info = 0; r.no = s.o; r.nd = s.d;
+  float xyz[3];
+  bool contributes = false;
+  float* spectrum_out = o.spectra ? o.spectra + size_t(s.slot) * RT_NBINS : nullptr;
+  if (found) {
+    const DevMaterial m = sc.materials[sc.objects[hit.obj].material];
+    if (b.integrator == RT_INT_ALBEDO) {
+      // first present of ambient / emitted / diffused / specular (src/integrators/albedo.rs:54-68)
+      uint32_t row = RT_NO_SPECTRUM;
+      if (m.present & RT_HAS_AMBIENT) row = m.ambient;
+      else if (m.present & RT_HAS_EMITTED) row = m.emitted;
+      else if (m.present & RT_HAS_DIFFUSED) row = m.diffused;
+      else if (m.present & RT_HAS_SPECULAR) row = m.specular;
+      if (row != RT_NO_SPECTRUM) { emit_sample(sc.spectra, row, s.chain, 0, xyz, spectrum_out); contributes = true; }
+    } else if (b.integrator == RT_INT_NORMAL) {
+      normal_sample(hit.n, xyz, spectrum_out);   // un-turned geometric normal (src/integrators/normal.rs:50)
+      contributes = true;
+    } else if (s.remaining != 0) {               // depth == 0 returns black after intersecting (random_walk.rs:68-70)
+      if (!first_hit && dot(hit.n, s.d) > 0.0) hit.n = neg(hit.n);
+      const uint32_t hit_index = b.max_depth - s.remaining;
+      if (m.type == RT_MAT_EMITTER) {            // src/scene.rs:56-62
+        if (m.present & RT_HAS_EMITTED) {
+          if (o.emit_counts) { r.emits = true; r.emit_info = uint32_t(m.emitted) | (hit_index << 8); }
+          else { emit_sample(sc.spectra, m.emitted, s.chain, hit_index, xyz, spectrum_out); contributes = true; }
+        }
+      } else if (m.type == RT_MAT_LAMBERTIAN) {  // src/scene.rs:63-79
+        if ((m.present & RT_HAS_AMBIENT) && s.remaining > 1) {
+          double r1, r2;
+          uniform_pair(b.seed, s.pixel, s.sample, hit_index, 1, r1, r2);
+          r.nd = normalize(cosine_direction(hit.n, r1, r2));
+          r.no = hit.p + hit.n * 1e-10;
+          chain_set(s.chain, hit_index, m.ambient);
+          r.alive = true;
+        }
+      } else if (s.remaining > 1) {              // Specular, src/scene.rs:80-112
+        r.nd = normalize(s.d - hit.n * (2.0 * dot(s.d, hit.n)));
+        r.no = hit.p + hit.n * 1e-10;
+        chain_set(s.chain, hit_index, (m.present & RT_HAS_SPECULAR) ? uint32_t(m.specular) : uint32_t(RT_NO_SPECTRUM));
+        r.alive = true;
+      }
+    }
+  }
+  if (contributes) {
+    o.contrib_x[s.slot] = xyz[0]; o.contrib_y[s.slot] = xyz[1]; o.contrib_z[s.slot] = xyz[2];
+  } else if (spectrum_out && !r.alive && !r.emits) {
+    for (int i = 0; i < RT_NBINS; ++i) spectrum_out[i] = 0.0f;
+  }
+  return r;
+}
+
+// Emitter hits of a wave go to the emit queue: one ballot, one atomic on the fill counter of the
+// region this chunk feeds. A wave that finds its region full marks what it reserved as unused and
+// forms its spectra in place instead. Must be reached by all lanes of the wave.
+__device__ __forceinline__ void append_emit(const DevScene& sc, const TraceOutputs& o, uint32_t chunk, bool deep, bool emits,
+                                            uint32_t emit_info, uint32_t slot, const Chain& chain) {
+  const unsigned long long emask = __ballot(emits);
+  if (!emask) return;
+  const uint32_t lane = __lane_id();
+  const uint32_t leader = uint32_t(__ffsll((long long)emask)) - 1u;
+  const uint32_t region = chunk % kShards, want = uint32_t(__popcll(emask));
+  uint32_t start = 0;
+  if (lane == leader) start = atomicAdd(o.emit_counts + region * kCountStride, want);
+  start = __shfl(start, int(leader));
+  const uint32_t rank = uint32_t(__popcll(emask & ((1ull << lane) - 1ull)));
+  const bool fits = start + want <= o.emit_region_entries;
+  if (emits) {
+    const uint32_t at = region * o.emit_region_entries + start + rank;
+    if (fits) {
+      o.emit.slot[at] = slot; o.emit.info[at] = emit_info; o.emit.chain0[at] = chain.a;
+      if (deep) o.emit.chain1[at] = chain.b;
+    } else {
+      if (start + rank < o.emit_region_entries) o.emit.slot[at] = RT_MISS;
+      float xyz[3];
+      emit_sample(sc.spectra, emit_info & 0xFFu, chain, emit_info >> 8, xyz, o.spectra ? o.spectra + size_t(slot) * RT_NBINS : nullptr);
+      o.contrib_x[slot] = xyz[0]; o.contrib_y[slot] = xyz[1]; o.contrib_z[slot] = xyz[2];
+    }
+  }
+}
+
+// Wave-level compaction of the lanes with `take` set into region chunk % kShards of a sharded
+// list: one ballot, one atomic per wave, takers packed in lane order. Returns the position the
+// lane's element goes to (RT_MISS for a lane that does not take part). Must be reached by all
+// lanes of the wave.
+__device__ __forceinline__ uint32_t reserve_in_region(uint32_t* counts, uint32_t region_entries, uint32_t chunk, bool take) {
+  const unsigned long long mask = __ballot(take);
+  if (!mask) return RT_MISS;
+  const uint32_t lane = __lane_id();
+  const uint32_t leader = uint32_t(__ffsll((long long)mask)) - 1u;
+  const uint32_t region = chunk % kShards;
+  uint32_t start = 0;
+  if (lane == leader) start = atomicAdd(counts + region * kCountStride, uint32_t(__popcll(mask)));
+  start = __shfl(start, int(leader));
+  return take ? region * region_entries + start + uint32_t(__popcll(mask & ((1ull << lane) - 1ull))) : RT_MISS;
+}
+
+// chunk -> position of its first entry's lane in the input queue; false for a lane past the fill
+__device__ __forceinline__ bool queue_position(const uint32_t* s_prefix, const uint32_t* s_fill, uint32_t region_entries,
+                                               uint32_t chunk, uint32_t& idx) {
+  const uint32_t lo = find_region(s_prefix, chunk);
+  const uint32_t within = (chunk - s_prefix[lo]) * kBlock + threadIdx.x;
+  idx = lo * region_entries + within;
+  return within < s_fill[lo];
+}
+
+// ------------------------------------------------------------------------------- the fused bounce kernel
+
+// One bounce for every path of a queue: closest hit, shading, append of the continuing paths.
+// PRIMARY: the path starts here (camera ray from the Philox jitter, or a caller ray); otherwise
+// its state comes from `in`. Used for scenes without meshes, where every lane does the same work.
 template <bool PRIMARY, int RULE, bool COUNT, bool STAGED>
 __global__ void __launch_bounds__(kBlock) RT_WAVES_ATTR
 bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_counts, uint32_t region_entries,
@@ -537,169 +742,266 @@ bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict
   uint32_t* stack;
   const uint4* node_words = stage_nodes<STAGED>(sc, lds_dynamic, stack);
   const bool deep = b.max_depth > 16;
-  uint32_t n_chunks;
-  if (PRIMARY) {
-    const uint32_t n = b.rays ? b.n_rays : b.n_local_pixels * b.n_samples;
-    n_chunks = (n + kBlock - 1) / kBlock;
-  } else {
-    n_chunks = number_chunks(in_counts, region_entries, s_chunk_prefix, s_region_fill);
-  }
+  const uint32_t n_start = b.rays ? b.n_rays : b.n_local_pixels * b.n_samples;
+  const uint32_t n_chunks = PRIMARY ? (n_start + kBlock - 1) / kBlock
+                                    : number_chunks(in_counts, region_entries, s_chunk_prefix, s_region_fill);
   uint32_t n_nodes = 0, n_prims = 0;
 
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     uint32_t idx;
     bool active;
-    if (PRIMARY) {
-      idx = chunk * kBlock + threadIdx.x;
-      active = idx < (b.rays ? b.n_rays : b.n_local_pixels * b.n_samples);
-    } else {
-      const uint32_t lo = find_region(s_chunk_prefix, chunk);
-      const uint32_t within = (chunk - s_chunk_prefix[lo]) * kBlock + threadIdx.x;
-      active = within < s_region_fill[lo];
-      idx = lo * region_entries + within;
-    }
-    V3 ro = mk(0, 0, 0), rd = mk(1, 0, 0);
-    uint32_t pixel = 0, sample = 0, slot = 0, remaining = 0;
-    Chain chain;
-    chain.a = make_uint4(0, 0, 0, 0); chain.b = make_uint4(0, 0, 0, 0);
-
+    if (PRIMARY) { idx = chunk * kBlock + threadIdx.x; active = idx < n_start; }
+    else active = queue_position(s_chunk_prefix, s_region_fill, region_entries, chunk, idx);
+    PathState ps;
+    ps.o = mk(0, 0, 0); ps.d = mk(1, 0, 0); ps.pixel = ps.sample = ps.slot = ps.remaining = 0;
+    ps.chain.a = make_uint4(0, 0, 0, 0); ps.chain.b = make_uint4(0, 0, 0, 0);
     if (active) {
-      if (PRIMARY) {
-        slot = idx;
-        remaining = b.integrator == RT_INT_RANDOM_WALK ? b.max_depth : 0;
-        if (b.rays) {
-          ro = ld3(b.rays + size_t(idx) * 6); rd = ld3(b.rays + size_t(idx) * 6 + 3);
-          pixel = b.pixel_base + idx; sample = b.sample0;
-        } else {
-          const uint32_t lp = idx % b.n_local_pixels;
-          sample = b.sample0 + idx / b.n_local_pixels;
-          uint32_t x, y;
-          active = local_pixel_to_xy(b, lp, x, y);
-          if (active) {
-            pixel = y * b.cam.width + x;
-            // evaluate_pixel_sample (src/integrators/integrator.rs:130-135) + Camera::get_ray (src/camera.rs:80-84)
-            double u0, u1;
-            uniform_pair(b.seed, pixel, sample, 0, 0, u0, u1);
-            const double fi = double(x) + u0 - 0.5, fj = double(y) + u1 - 0.5;
-            const V3 p1 = ld3(b.cam.p1), p2 = ld3(b.cam.p2), p3 = ld3(b.cam.p3), f = ld3(b.cam.focus);
-            const V3 right = ((p2 - p1) * fi) / double(b.cam.width);
-            const V3 down = ((p3 - p1) * fj) / double(b.cam.height);
-            ro = f;
-            rd = normalize(((p1 + right) + down) - f);
-          }
-        }
-      } else {
-        ro = mk(in.ox[idx], in.oy[idx], in.oz[idx]);
-        rd = mk(in.dx[idx], in.dy[idx], in.dz[idx]);
-        pixel = in.pixel[idx]; sample = in.sample[idx]; slot = in.slot[idx]; remaining = in.remaining[idx];
-        chain.a = in.chain0[idx];
-        if (deep) chain.b = in.chain1[idx];
-      }
+      if (PRIMARY) active = start_path(b, idx, ps);
+      else load_path(in, idx, deep, ps);
     }
-
-    bool alive = false;      // continues to the next bounce
-    bool emits = false;      // ended on an emitter: its spectrum is formed by emit_kernel
-    uint32_t emit_info = 0;
-    V3 no = ro, nd = rd;
+    Shaded sh;
+    sh.alive = false; sh.emits = false; sh.emit_info = 0; sh.no = ps.o; sh.nd = ps.d;
     if (active) {
       Hit hit;
-      const bool found = closest_hit<RULE, COUNT>(sc, node_words, ro, rd, stack, hit, n_nodes, n_prims);
-      float xyz[3];
-      bool contributes = false;
-      float* spectrum_out = o.spectra ? o.spectra + size_t(slot) * RT_NBINS : nullptr;
-      if (found) {
-        const DevMaterial m = sc.materials[sc.objects[hit.obj].material];
-        if (b.integrator == RT_INT_ALBEDO) {
-          // first present of ambient / emitted / diffused / specular (src/integrators/albedo.rs:54-68)
-          uint32_t row = RT_NO_SPECTRUM;
-          if (m.present & RT_HAS_AMBIENT) row = m.ambient;
-          else if (m.present & RT_HAS_EMITTED) row = m.emitted;
-          else if (m.present & RT_HAS_DIFFUSED) row = m.diffused;
-          else if (m.present & RT_HAS_SPECULAR) row = m.specular;
-          if (row != RT_NO_SPECTRUM) { emit_sample(sc.spectra, row, chain, 0, xyz, spectrum_out); contributes = true; }
-        } else if (b.integrator == RT_INT_NORMAL) {
-          normal_sample(hit.n, xyz, spectrum_out);   // un-turned geometric normal (src/integrators/normal.rs:50)
-          contributes = true;
-        } else if (remaining != 0) {                 // depth == 0 returns black after intersecting (random_walk.rs:68-70)
-          // a primary hit keeps its normal as is (random_walk.rs:74); later hits turn it against the ray (scene.rs:30-32)
-          if (!PRIMARY && dot(hit.n, rd) > 0.0) hit.n = neg(hit.n);
-          const uint32_t hit_index = b.max_depth - remaining;
-          if (m.type == RT_MAT_EMITTER) {            // src/scene.rs:56-62
-            if (m.present & RT_HAS_EMITTED) {
-              if (o.emit_counts) { emits = true; emit_info = uint32_t(m.emitted) | (hit_index << 8); }
-              else { emit_sample(sc.spectra, m.emitted, chain, hit_index, xyz, spectrum_out); contributes = true; }
-            }
-          } else if (m.type == RT_MAT_LAMBERTIAN) {  // src/scene.rs:63-79
-            if ((m.present & RT_HAS_AMBIENT) && remaining > 1) {
-              double r1, r2;
-              uniform_pair(b.seed, pixel, sample, hit_index, 1, r1, r2);
-              nd = normalize(cosine_direction(hit.n, r1, r2));
-              no = hit.p + hit.n * 1e-10;
-              chain_set(chain, hit_index, m.ambient);
-              alive = true;
-            }
-          } else if (remaining > 1) {                // Specular, src/scene.rs:80-112
-            nd = normalize(rd - hit.n * (2.0 * dot(rd, hit.n)));
-            no = hit.p + hit.n * 1e-10;
-            chain_set(chain, hit_index, (m.present & RT_HAS_SPECULAR) ? uint32_t(m.specular) : uint32_t(RT_NO_SPECTRUM));
-            alive = true;
-          }
-        }
-      }
-      if (contributes) {
-        o.contrib_x[slot] = xyz[0]; o.contrib_y[slot] = xyz[1]; o.contrib_z[slot] = xyz[2];
-      } else if (spectrum_out && !alive && !emits) {
-        for (int i = 0; i < RT_NBINS; ++i) spectrum_out[i] = 0.0f;
-      }
+      const bool found = closest_hit<RULE, COUNT>(sc, node_words, ps.o, ps.d, stack, hit, n_nodes, n_prims);
+      sh = shade_hit(sc, b, o, found, hit, PRIMARY, ps);
     }
-
-    // emitter hits: same ballot-and-one-atomic append, into the emit queue. A wave that finds its
-    // region full marks what it reserved as unused and forms its spectra in place instead.
-    const unsigned long long emask = __ballot(emits);
-    if (emask) {
-      const uint32_t lane = __lane_id();
-      const uint32_t leader = uint32_t(__ffsll((long long)emask)) - 1u;
-      const uint32_t region = chunk % kShards, want = uint32_t(__popcll(emask));
-      uint32_t start = 0;
-      if (lane == leader) start = atomicAdd(o.emit_counts + region * kCountStride, want);
-      start = __shfl(start, int(leader));
-      const uint32_t rank = uint32_t(__popcll(emask & ((1ull << lane) - 1ull)));
-      const bool fits = start + want <= o.emit_region_entries;
-      if (emits) {
-        const uint32_t at = region * o.emit_region_entries + start + rank;
-        if (fits) {
-          o.emit.slot[at] = slot; o.emit.info[at] = emit_info; o.emit.chain0[at] = chain.a;
-          if (deep) o.emit.chain1[at] = chain.b;
-        } else {
-          if (start + rank < o.emit_region_entries) o.emit.slot[at] = RT_MISS;
-          float xyz[3];
-          emit_sample(sc.spectra, emit_info & 0xFFu, chain, emit_info >> 8, xyz, o.spectra ? o.spectra + size_t(slot) * RT_NBINS : nullptr);
-          o.contrib_x[slot] = xyz[0]; o.contrib_y[slot] = xyz[1]; o.contrib_z[slot] = xyz[2];
-        }
-      }
-    }
-
-    // wave-level compaction: one ballot, one atomic per wave on the fill counter of the output
-    // region this chunk feeds, survivors packed in lane order
-    const unsigned long long mask = __ballot(alive);
-    if (mask) {
-      const uint32_t lane = __lane_id();
-      const uint32_t leader = uint32_t(__ffsll((long long)mask)) - 1u;
-      const uint32_t region = chunk % kShards;
-      uint32_t start = 0;
-      if (lane == leader) start = atomicAdd(out_counts + region * kCountStride, uint32_t(__popcll(mask)));
-      start = __shfl(start, int(leader));
-      if (alive) {
-        const uint32_t at = region * region_entries + start + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
-        queue_store(out, at, no, nd, pixel, sample, slot, remaining - 1, chain, deep);
-      }
-    }
+    append_emit(sc, o, chunk, deep, sh.emits, sh.emit_info, ps.slot, ps.chain);
+    const uint32_t at = reserve_in_region(out_counts, region_entries, chunk, sh.alive);
+    if (sh.alive) queue_store(out, at, sh.no, sh.nd, ps.pixel, ps.sample, ps.slot, ps.remaining - 1, ps.chain, deep);
   }
 
   if (COUNT) {
     unsigned long long a = n_nodes, c = n_prims;
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); c += __shfl_down(c, off); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&counters->nodes, a); atomicAdd(&counters->prims, c); }
+  }
+}
+
+// ------------------------------------------------------------------------------- the two-kernel pipeline
+
+// Dense half of a bounce. START: creates the batch's paths (level 0). Otherwise: shades the hits
+// recorded for the paths of `in` and produces the continuing paths. Either way every path that goes
+// on is appended to `out` with the closest hit of its new ray among spheres and lone triangles, and
+// listed for traverse_kernel if that ray meets the bounding box of a mesh.
+template <bool START>
+__global__ void __launch_bounds__(kBlock)
+shade_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_counts, uint32_t region_entries,
+             PathQueue out, uint32_t* __restrict__ out_counts, MeshList mesh, TraceOutputs o) {
+  __shared__ uint32_t s_chunk_prefix[kShards + 1];
+  __shared__ uint32_t s_region_fill[kShards];
+  const bool deep = b.max_depth > 16;
+  const uint32_t n_start = b.rays ? b.n_rays : b.n_local_pixels * b.n_samples;
+  const uint32_t n_chunks = START ? (n_start + kBlock - 1) / kBlock
+                                  : number_chunks(in_counts, region_entries, s_chunk_prefix, s_region_fill);
+
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    uint32_t idx;
+    bool active;
+    if (START) { idx = chunk * kBlock + threadIdx.x; active = idx < n_start; }
+    else active = queue_position(s_chunk_prefix, s_region_fill, region_entries, chunk, idx);
+    PathState ps;
+    ps.o = mk(0, 0, 0); ps.d = mk(1, 0, 0); ps.pixel = ps.sample = ps.slot = ps.remaining = 0;
+    ps.chain.a = make_uint4(0, 0, 0, 0); ps.chain.b = make_uint4(0, 0, 0, 0);
+    Shaded sh;
+    sh.alive = false; sh.emits = false; sh.emit_info = 0; sh.no = ps.o; sh.nd = ps.d;
+    uint32_t remaining_next = 0;
+    if (START) {
+      if (active) active = start_path(b, idx, ps);
+      sh.alive = active; sh.no = ps.o; sh.nd = ps.d;
+      remaining_next = ps.remaining;
+    } else if (active) {
+      load_path(in, idx, deep, ps);
+      Hit hit;
+      hit.obj = in.hit_obj[idx];
+      const bool found = hit.obj != RT_MISS;
+      if (found) {
+        hit.t = in.hit_t[idx]; hit.prim = in.hit_prim[idx];
+        hit_geometry(sc, sc.objects[hit.obj], ps.o, ps.d, normalize(ps.d), hit.t, in.hit_raw[idx], in.hit_slot[idx], hit.p, hit.n);
+      }
+      const bool first_hit = b.integrator != RT_INT_RANDOM_WALK || ps.remaining == b.max_depth;
+      sh = shade_hit(sc, b, o, found, hit, first_hit, ps);
+      remaining_next = ps.remaining - 1;
+    }
+    if (!START) append_emit(sc, o, chunk, deep, sh.emits, sh.emit_info, ps.slot, ps.chain);
+    const uint32_t at = reserve_in_region(out_counts, region_entries, chunk, sh.alive);
+    bool meets_mesh = false;
+    if (sh.alive) {
+      queue_store(out, at, sh.no, sh.nd, ps.pixel, ps.sample, ps.slot, remaining_next, ps.chain, deep);
+      Prelim pre;
+      meets_mesh = simple_objects(sc, sh.no, sh.nd, normalize(sh.nd), pre);
+      out.hit_t[at] = pre.t; out.hit_raw[at] = pre.t_raw; out.hit_obj[at] = pre.obj;
+      out.hit_prim[at] = 0; out.hit_slot[at] = 0;
+    }
+    const uint32_t listed = reserve_in_region(mesh.counts, region_entries, chunk, meets_mesh);
+    if (meets_mesh) mesh.entries[listed] = at;
+  }
+}
+
+// Sparse half of a bounce: BVH traversal for the listed queue entries, by persistent waves. Each
+// wave owns a contiguous share of the list; a lane that has finished its ray takes the next entry
+// of the share, so a wave keeps working at near-full width while some of its rays take ten times
+// as many steps as others. Lanes are serviced (retired, moved to the next mesh, refilled) in groups
+// of at least kRefillLanes to keep that bookkeeping off the traversal's critical path.
+constexpr uint32_t kRefillLanes = 16;
+constexpr uint32_t kMinWaveShare = 512;   // entries; a smaller share leaves too little to refill from
+
+template <int RULE, bool COUNT, bool STAGED>
+__global__ void __launch_bounds__(kBlock) RT_WAVES_ATTR
+traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries, TraversalCounters* counters) {
+  extern __shared__ uint4 lds_dynamic[];
+  __shared__ uint32_t s_prefix[kShards + 1];   // list entries before each region
+  uint32_t* stack;
+  const uint4* node_words = stage_nodes<STAGED>(sc, lds_dynamic, stack);
+  if (threadIdx.x < kShards) {
+    uint32_t fill = mesh.counts[threadIdx.x * kCountStride];
+    fill = fill < region_entries ? fill : region_entries;
+    uint32_t scan = fill;
+    for (int off = 1; off < int(kShards); off <<= 1) {
+      const uint32_t up = __shfl_up(scan, off);
+      if (int(threadIdx.x) >= off) scan += up;
+    }
+    s_prefix[threadIdx.x + 1] = scan;
+    if (threadIdx.x == 0) s_prefix[0] = 0;
+  }
+  __syncthreads();
+  const uint32_t total = s_prefix[kShards];
+  const uint32_t n_waves = gridDim.x * (kBlock / 64);
+  uint32_t share = (total + n_waves - 1) / n_waves;
+  share = share < kMinWaveShare ? kMinWaveShare : share;
+  share = (share + 63u) & ~63u;
+  const uint64_t begin = uint64_t(blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * share;
+  uint32_t next = begin < total ? uint32_t(begin) : total;
+  const uint32_t end = begin + share < total ? uint32_t(begin + share) : total;
+
+  constexpr uint32_t kDone = RT_REF_NONE;  // has the leaf bit set, so it also ends the node loop
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t n_nodes = 0, n_prims = 0;
+  uint32_t entry = RT_MISS;                // queue entry whose ray this lane is working on
+  V3 o = mk(0, 0, 0), dn = mk(1, 0, 0);
+  BoxRay br = {};
+  uint32_t m = 0;                          // which mesh of the scene the lane is in
+  uint32_t root = 0, first_tri = 0;
+  MeshHit mh;                              // best inside the current mesh
+  mh.t = INFINITY; mh.t_raw = 0.0; mh.index = RT_MISS; mh.slot = 0;
+  double best_t = 0.0, best_raw = 0.0;     // best over the meshes done so far
+  uint32_t best_obj = RT_MISS, best_prim = 0, best_slot = 0;
+  uint32_t cur = kDone;
+  int sp = 0;
+
+  for (;;) {
+    // ---- service: every lane whose traversal has ended
+    if (cur == kDone && entry != RT_MISS) {
+      // meshes are visited in scene order, so strict '<' keeps the earlier object on a tie
+      if (mh.index != RT_MISS && (best_obj == RT_MISS || mh.t < best_t)) {
+        best_t = mh.t; best_raw = mh.t_raw; best_obj = sc.mesh_objects[m]; best_prim = mh.index; best_slot = mh.slot;
+      }
+      if (++m == sc.n_meshes) {
+        if (best_obj != RT_MISS) {
+          // fold into what shade_kernel found among spheres and lone triangles: smaller t wins, the earlier object on a tie
+          const uint32_t pre_obj = q.hit_obj[entry];
+          const double pre_t = q.hit_t[entry];
+          if (pre_obj == RT_MISS || best_t < pre_t || (best_t == pre_t && best_obj < pre_obj)) {
+            q.hit_t[entry] = best_t; q.hit_raw[entry] = best_raw; q.hit_obj[entry] = best_obj;
+            q.hit_prim[entry] = best_prim; q.hit_slot[entry] = best_slot;
+          }
+        }
+        entry = RT_MISS;
+      }
+    }
+    const unsigned long long idle = __ballot(entry == RT_MISS);
+    if (idle && next < end) {
+      const uint32_t g = next + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+      if (entry == RT_MISS && g < end) {
+        const uint32_t region = find_region(s_prefix, g);
+        entry = mesh.entries[region * region_entries + (g - s_prefix[region])];
+        o = mk(q.ox[entry], q.oy[entry], q.oz[entry]);
+        dn = normalize(mk(q.dx[entry], q.dy[entry], q.dz[entry]));  // src/geometry/ray.rs:45
+        m = 0; best_obj = RT_MISS;
+      }
+      const uint32_t taken = uint32_t(__popcll(idle));
+      next = end - next < taken ? end : next + taken;
+    }
+    if (cur == kDone && entry != RT_MISS) {   // enter mesh m
+      const DevObject ob = sc.objects[sc.mesh_objects[m]];
+      br = make_box_ray(o, dn, ob);
+      root = ob.root; first_tri = ob.first;
+      mh.t = INFINITY; mh.t_raw = 0.0; mh.index = RT_MISS; mh.slot = 0;
+      cur = 0; sp = 0;
+    }
+    if (__ballot(entry != RT_MISS) == 0) break;
+    const bool refillable = next < end;
+
+    // ---- traverse until enough lanes can be given new work
+    for (;;) {
+      while (!(cur & RT_LEAF_FLAG)) {
+        const uint4* np = node_words + (size_t(root) + cur) * 4;
+        const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+        if (COUNT) ++n_nodes;
+        const float lo0[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
+        const float hi0[3] = {__uint_as_float(w0.w), __uint_as_float(w1.x), __uint_as_float(w1.y)};
+        const float lo1[3] = {__uint_as_float(w1.z), __uint_as_float(w1.w), __uint_as_float(w2.x)};
+        const float hi1[3] = {__uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w)};
+        const uint32_t ref0 = w3.x, ref1 = w3.y, min0 = w3.z, min1 = w3.w;
+        const float tmax = RULE == RT_HIT_NEAREST ? __double2float_ru(mh.t) * 1.000002f : INFINITY;
+        float tn0, tn1;
+        bool h0 = ref0 != RT_REF_NONE && slab32(lo0, hi0, br, tmax, tn0);
+        bool h1 = ref1 != RT_REF_NONE && slab32(lo1, hi1, br, tmax, tn1);
+        if (RULE == RT_HIT_FIRST_INDEX) { h0 = h0 && min0 < mh.index; h1 = h1 && min1 < mh.index; }
+        if (h0 && h1) {
+          const bool swap = RULE == RT_HIT_FIRST_INDEX ? (min1 < min0) : (tn1 < tn0);
+          stack[(sp++) * kBlock] = swap ? ref0 : ref1;
+          cur = swap ? ref1 : ref0;
+        } else if (h0) {
+          cur = ref0;
+        } else if (h1) {
+          cur = ref1;
+        } else {
+          cur = sp ? stack[(--sp) * kBlock] : kDone;
+        }
+      }
+      if (cur != kDone) {
+        const uint32_t first = (cur & ~RT_LEAF_FLAG) >> 4, cnt = cur & 15u;
+        for (uint32_t i = 0; i < cnt; ++i) {
+          const DevMeshTri* tp = sc.mesh_tris + first_tri + first + i;
+#ifdef RT_TRI_FILTER
+          const DevTriFilter f = sc.mesh_filters[first_tri + first + i];
+          const uint32_t index = f.index;
+#else
+          const uint32_t index = tp->index;
+#endif
+          if (RULE == RT_HIT_FIRST_INDEX && index >= mh.index) break;  // a leaf is sorted by index
+          if (COUNT) ++n_prims;
+#ifdef RT_TRI_FILTER
+          const float tmax = RULE == RT_HIT_NEAREST ? __double2float_ru(mh.t) * 1.000002f : INFINITY;
+          if (!triangle_maybe_hit(f, br, tmax)) continue;
+#endif
+          const double2* v = reinterpret_cast<const double2*>(tp->v);
+          const double2 a = v[0], b = v[1], c = v[2], e = v[3];
+          const double last = tp->v[8];
+          double t_raw, t;
+          if (triangle_hit(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), mk(e.x, e.y, last), o, dn, t_raw, t)) {
+            if (RULE == RT_HIT_FIRST_INDEX) {
+              mh.t = t; mh.t_raw = t_raw; mh.index = index; mh.slot = first + i;
+              break;
+            } else if (t < mh.t || (t == mh.t && index < mh.index)) {
+              mh.t = t; mh.t_raw = t_raw; mh.index = index; mh.slot = first + i;
+            }
+          }
+        }
+        cur = sp ? stack[(--sp) * kBlock] : kDone;
+      }
+      const bool done = cur == kDone;
+      if (__ballot(!done) == 0) break;
+      const bool serviceable = done && (refillable || (entry != RT_MISS && m + 1 < sc.n_meshes));
+      if (uint32_t(__popcll(__ballot(serviceable))) >= kRefillLanes) break;
+    }
+  }
+
+  if (COUNT) {
+    unsigned long long a = n_nodes, c = n_prims;
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); c += __shfl_down(c, off); }
+    if (lane == 0) { atomicAdd(&counters->nodes, a); atomicAdd(&counters->prims, c); }
   }
 }
 
@@ -847,6 +1149,42 @@ void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const u
   const dim3 grid(grid_for(size_t(max_in) + size_t(kShards) * kBlock));
   const size_t lds = stack_bytes(sc);
   RTMI_DISPATCH(bounce_kernel, false, sc, b, in, in_counts, region_entries, out, out_counts, o, counters);
+}
+
+void launch_generate(const DevScene& sc, const BatchDesc& b, PathQueue out, uint32_t* out_counts, uint32_t region_entries,
+                     MeshList mesh, hipStream_t s) {
+  const size_t n = b.rays ? size_t(b.n_rays) : size_t(b.n_local_pixels) * b.n_samples;
+  if (n == 0) return;
+  hipLaunchKernelGGL(shade_kernel<true>, dim3(grid_for(n)), kBlock, 0, s, sc, b, PathQueue{}, (const uint32_t*)nullptr,
+                     region_entries, out, out_counts, mesh, TraceOutputs{});
+}
+
+void launch_shade(const DevScene& sc, const BatchDesc& b, PathQueue in, const uint32_t* in_counts, uint32_t max_in,
+                  PathQueue out, uint32_t* out_counts, uint32_t region_entries, MeshList mesh, TraceOutputs o, hipStream_t s) {
+  if (max_in == 0) return;
+  hipLaunchKernelGGL(shade_kernel<false>, dim3(grid_for(size_t(max_in) + size_t(kShards) * kBlock)), kBlock, 0, s, sc, b, in,
+                     in_counts, region_entries, out, out_counts, mesh, o);
+}
+
+void launch_traverse(const DevScene& sc, PathQueue q, MeshList mesh, uint32_t max_in, uint32_t region_entries,
+                     TraversalCounters* counters, hipStream_t s) {
+  if (max_in == 0 || sc.n_meshes == 0) return;
+  // enough waves to fill the chip twice over when the list is long, one share of kMinWaveShare entries each when it is short
+  const size_t waves = (size_t(max_in) + kMinWaveShare - 1) / kMinWaveShare;
+  const size_t blocks = (waves + kBlock / 64 - 1) / (kBlock / 64);
+  const dim3 grid(uint32_t(blocks < 1 ? 1 : (blocks < 2048 ? blocks : 2048)));
+  const size_t lds = stack_bytes(sc);
+  const int sel = (sc.hit_rule == RT_HIT_NEAREST ? 4 : 0) | (counters ? 2 : 0) | (sc.lds_nodes ? 1 : 0);
+  switch (sel) {
+    case 0: hipLaunchKernelGGL((traverse_kernel<0, false, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, counters); break;
+    case 1: hipLaunchKernelGGL((traverse_kernel<0, false, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, counters); break;
+    case 2: hipLaunchKernelGGL((traverse_kernel<0, true, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, counters); break;
+    case 3: hipLaunchKernelGGL((traverse_kernel<0, true, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, counters); break;
+    case 4: hipLaunchKernelGGL((traverse_kernel<1, false, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, counters); break;
+    case 5: hipLaunchKernelGGL((traverse_kernel<1, false, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, counters); break;
+    case 6: hipLaunchKernelGGL((traverse_kernel<1, true, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, counters); break;
+    default: hipLaunchKernelGGL((traverse_kernel<1, true, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, counters); break;
+  }
 }
 
 void launch_intersect(const DevScene& sc, const void* rays_, size_t n, void* hits_, TraversalCounters* counters, hipStream_t s) {

@@ -36,7 +36,11 @@ struct DevObject {
   uint32_t pad[3];
   double center[3];    // models: the point the node boxes are relative to
   double radius;       // models: all triangles lie within this distance of center
+  float box_lo[3];     // models: binary32 box around the whole mesh, relative to center, rounded outward
+  float box_hi[3];
+  uint32_t pad2[2];
 };
+static_assert(sizeof(DevObject) == 96, "DevObject must be 96 bytes");
 
 struct DevSphere {
   double l2w[12];
@@ -94,12 +98,13 @@ struct DevScene {
   const DevTriFilter* mesh_filters;   // parallel to mesh_tris
   const DevMaterial* materials;
   const float* spectra;       // n_spectra x 60
+  const uint32_t* mesh_objects;  // positions in `objects` of the models, ascending
+  uint32_t n_meshes;
   uint32_t n_objects;
   uint32_t hit_rule;
   uint32_t stack_entries;     // LDS traversal stack depth per lane
   uint32_t n_spectra;
   uint32_t lds_nodes;         // > 0: all BVH nodes of the scene (this many) are staged into LDS by every workgroup
-  uint32_t pad;
 };
 
 struct DevCamera {

@@ -74,7 +74,7 @@ struct rtmi_ctx {
   size_t queue_paths = 0;
   bool queue_deep = false;
   DevBuf contrib, counts, tiles, stats, rays, hits, spectra_out, image;
-  DevBuf emit_mem;
+  DevBuf emit_mem, mesh_list;
   EmitQueue emit{};
   uint32_t emit_region_entries = 0;
   size_t emit_paths = 0;
@@ -84,16 +84,20 @@ struct rtmi_ctx {
 struct rtmi_scene {
   rtmi_ctx* ctx = nullptr;
   DevScene dev{};
-  DevBuf objects, spheres, top_tris, nodes, mesh_tris, mesh_filters, materials, spectra;
+  DevBuf objects, spheres, top_tris, nodes, mesh_tris, mesh_filters, materials, spectra, mesh_objects;
   rtmi_scene_info info{};
   // bookkeeping of the last render_accumulate, completed by rtmi_render_collect_stats
   rtmi_stats pending{};
   bool counting = false;
+  bool fused_only = false;   // RTMI_PIPELINE=fused: one kernel per bounce even with meshes (for A/B measurements)
 };
 
 namespace {
 
-constexpr uint64_t kDefaultBatchPaths = 1ull << 24;  // 16 Mi path slots, about 3.5 GB of workspace
+// Default number of path slots per batch of launches: 128 Mi, about 31 GB of workspace out of 288 GB. A launch over a
+// deep queue level is bound by the longest traversals in it, not by how many paths it holds, so the fewer and larger the
+// batches, the fewer of those tails a render pays for (1080p x 64 spp fits one batch).
+constexpr uint64_t kDefaultBatchPaths = 1ull << 27;
 
 int bind(const rtmi_ctx* ctx) {
   HIP_TRY(hipSetDevice(ctx->device));
@@ -110,12 +114,16 @@ PathQueue carve_queue(void* base, size_t paths, bool deep) {
   q.slot = (uint32_t*)take(paths * 4); q.remaining = (uint32_t*)take(paths * 4);
   q.chain0 = (uint4*)take(paths * 16);
   q.chain1 = deep ? (uint4*)take(paths * 16) : nullptr;
+  q.hit_t = (double*)take(paths * 8); q.hit_raw = (double*)take(paths * 8);
+  q.hit_obj = (uint32_t*)take(paths * 4); q.hit_prim = (uint32_t*)take(paths * 4); q.hit_slot = (uint32_t*)take(paths * 4);
   return q;
 }
 
-size_t queue_bytes(size_t entries, bool deep) { return entries * (6 * 8 + 4 * 4 + 16 + (deep ? 16 : 0)) + 12 * 256; }
+size_t queue_bytes(size_t entries, bool deep) { return entries * (6 * 8 + 4 * 4 + 16 + (deep ? 16 : 0) + 2 * 8 + 3 * 4) + 17 * 256; }
 constexpr size_t kCountLevelWords = size_t(kShards) * kCountStride;            // uint32 words per queue level
-constexpr size_t kCountBytes = (RT_MAX_DEPTH + 3) * kCountLevelWords * sizeof(uint32_t);  // queue levels + the emit queue
+// fill counters: path-queue levels 0..depth+1, the emit queue, then one mesh list per level
+constexpr size_t kCountLevels = 2 * RT_MAX_DEPTH + 5;
+constexpr size_t kCountBytes = kCountLevels * kCountLevelWords * sizeof(uint32_t);
 
 int ensure_workspace(rtmi_ctx* ctx, size_t paths, bool deep, bool want_queues) {
   if (want_queues && (paths > ctx->queue_paths || (deep && !ctx->queue_deep))) {
@@ -126,6 +134,8 @@ int ensure_workspace(rtmi_ctx* ctx, size_t paths, bool deep, bool want_queues) {
       if (int rc = ctx->queue_mem[i].reserve(queue_bytes(queue_entries(p), d))) return rc;
       ctx->queue[i] = carve_queue(ctx->queue_mem[i].p, queue_entries(p), d);
     }
+    ctx->mesh_list.release();
+    if (int rc = ctx->mesh_list.reserve(queue_entries(p) * sizeof(uint32_t))) return rc;
     ctx->queue_paths = p; ctx->queue_deep = d;
   }
   if (want_queues && (paths > ctx->emit_paths || (deep && !ctx->emit_deep))) {
@@ -212,7 +222,7 @@ DevCamera to_dev_camera(const rtmi_camera& c) {
   return d;
 }
 
-// Runs primary + bounce launches for one batch and leaves per-slot contributions in ctx->contrib.
+// Runs the launches of one batch and leaves per-slot contributions in ctx->contrib.
 int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra_out, hipStream_t stream,
               KernelClock& clock, uint32_t& launches) {
   rtmi_ctx* ctx = sc->ctx;
@@ -223,27 +233,51 @@ int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra
   TraversalCounters* counters = sc->counting ? &ds->trav : nullptr;
   const uint32_t depth = b.integrator == RT_INT_RANDOM_WALK ? b.max_depth : 0;
   // queue level k holds the paths that enter bounce k; its kShards fill counters sit at counts + k * kCountLevelWords;
-  // the emit queue's counters follow the last level
-  HIP_TRY(hipMemsetAsync(counts, 0, (size_t(depth) + 3) * kCountLevelWords * sizeof(uint32_t), stream));
+  // the emit queue's counters follow the last level, the per-level mesh lists' counters follow those
+  const size_t emit_level = size_t(depth) + 2, mesh_level0 = emit_level + 1;
+  const bool split = sc->dev.n_meshes > 0 && !sc->fused_only;
+  const size_t levels_used = split ? mesh_level0 + std::max<uint32_t>(depth, 1) : mesh_level0;
+  HIP_TRY(hipMemsetAsync(counts, 0, levels_used * kCountLevelWords * sizeof(uint32_t), stream));
   const bool deep = depth > 16;
   if (depth >= 1 && ctx->emit_paths >= n_paths && (!deep || ctx->emit_deep) && !getenv("RTMI_INLINE_EMIT")) {
-    o.emit = ctx->emit; o.emit_counts = counts + (size_t(depth) + 2) * kCountLevelWords; o.emit_region_entries = ctx->emit_region_entries;
+    o.emit = ctx->emit; o.emit_counts = counts + emit_level * kCountLevelWords; o.emit_region_entries = ctx->emit_region_entries;
   }
   HIP_TRY(hipMemsetAsync(contrib, 0, n_paths * 3 * sizeof(float), stream));
   const uint32_t region_entries = region_chunks(ctx->queue_paths) * kBlock;
-  clock.begin();
-  launch_primary(sc->dev, b, ctx->queue[0], counts + kCountLevelWords, region_entries, o, counters, stream);
-  clock.end();
-  ++launches;
-  for (uint32_t k = 1; k < depth; ++k) {
+  auto level_counts = [&](size_t k) { return counts + k * kCountLevelWords; };
+  if (!split) {
     clock.begin();
-    launch_bounce(sc->dev, b, ctx->queue[(k - 1) & 1], counts + k * kCountLevelWords, uint32_t(n_paths), ctx->queue[k & 1],
-                  counts + (k + 1) * kCountLevelWords, region_entries, o, counters, stream);
+    launch_primary(sc->dev, b, ctx->queue[0], level_counts(1), region_entries, o, counters, stream);
     clock.end();
     ++launches;
+    for (uint32_t k = 1; k < depth; ++k) {
+      clock.begin();
+      launch_bounce(sc->dev, b, ctx->queue[(k - 1) & 1], level_counts(k), uint32_t(n_paths), ctx->queue[k & 1],
+                    level_counts(k + 1), region_entries, o, counters, stream);
+      clock.end();
+      ++launches;
+    }
+  } else {
+    // level k lives in queue[k & 1]; generate fills level 0, then per level: traverse, shade (which fills level k + 1)
+    auto mesh_list = [&](size_t k) { return MeshList{ctx->mesh_list.as<uint32_t>(), level_counts(mesh_level0 + k)}; };
+    clock.begin();
+    launch_generate(sc->dev, b, ctx->queue[0], level_counts(0), region_entries, mesh_list(0), stream);
+    clock.end();
+    ++launches;
+    const uint32_t levels = std::max<uint32_t>(depth, 1);   // albedo / normal integrators: the primary hit only
+    for (uint32_t k = 0; k < levels; ++k) {
+      clock.begin();
+      launch_traverse(sc->dev, ctx->queue[k & 1], mesh_list(k), uint32_t(n_paths), region_entries, counters, stream);
+      clock.end();
+      clock.begin();
+      launch_shade(sc->dev, b, ctx->queue[k & 1], level_counts(k), uint32_t(n_paths), ctx->queue[(k + 1) & 1], level_counts(k + 1),
+                   region_entries, mesh_list(k + 1 < levels ? k + 1 : k), o, stream);
+      clock.end();
+      launches += 2;
+    }
   }
   launch_emit(sc->dev, o, deep, uint32_t(n_paths), stream);
-  if (depth > 1) launch_sum_counts(counts + kCountLevelWords, depth - 1, &ds->bounce_segments, stream);
+  if (depth > 1) launch_sum_counts(level_counts(1), depth - 1, &ds->bounce_segments, stream);
   HIP_TRY(hipGetLastError());
   return RTMI_OK;
 }
@@ -393,6 +427,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   std::vector<BvhNode> nodes;
   std::vector<DevMeshTri> mesh_tris;
   std::vector<DevTriFilter> mesh_filters;
+  std::vector<uint32_t> mesh_objects;
   uint32_t max_depth = 0;
   for (uint32_t i = 0; i < d->n_objects; ++i) {
     const rtmi_object& o = d->objects[i];
@@ -426,8 +461,15 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
       dobj.first = uint32_t(mesh_tris.size());
       std::memcpy(dobj.center, bb.center, sizeof dobj.center);
       dobj.radius = bb.radius;
+      for (int k = 0; k < 3; ++k) {   // union of the root's two child boxes, which are already padded and rounded outward
+        const BvhNode& r = bb.nodes[0];
+        dobj.box_lo[k] = std::min(r.lo0[k], r.lo1[k]);
+        dobj.box_hi[k] = std::max(r.hi0[k], r.hi1[k]);
+      }
+      mesh_objects.push_back(i);
       nodes.insert(nodes.end(), bb.nodes.begin(), bb.nodes.end());
       mesh_tris.insert(mesh_tris.end(), bb.tris.begin(), bb.tris.end());
+#ifdef RT_TRI_FILTER
       for (const DevMeshTri& t : bb.tris) {
         DevTriFilter f{};
         float scale = 0.0f;
@@ -441,6 +483,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
         f.index = t.index;
         mesh_filters.push_back(f);
       }
+#endif
       max_depth = std::max(max_depth, bb.max_depth);
     } else {
       return fail(RTMI_UNSUPPORTED, "object %u has unknown kind %u", i, o.kind);
@@ -462,7 +505,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   int rc;
   if ((rc = upload(s->objects, objects)) || (rc = upload(s->spheres, spheres)) || (rc = upload(s->top_tris, top_tris)) ||
       (rc = upload(s->nodes, nodes)) || (rc = upload(s->mesh_tris, mesh_tris)) || (rc = upload(s->mesh_filters, mesh_filters)) ||
-      (rc = upload(s->materials, mats)) ||
+      (rc = upload(s->materials, mats)) || (rc = upload(s->mesh_objects, mesh_objects)) ||
       (rc = upload(s->spectra, spectra))) {
     rtmi_scene_destroy(s.release());
     return rc;
@@ -472,12 +515,14 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   s->dev.mesh_tris = s->mesh_tris.as<DevMeshTri>(); s->dev.mesh_filters = s->mesh_filters.as<DevTriFilter>();
   s->dev.materials = s->materials.as<DevMaterial>();
   s->dev.spectra = s->spectra.as<float>();
+  s->dev.mesh_objects = s->mesh_objects.as<uint32_t>(); s->dev.n_meshes = uint32_t(mesh_objects.size());
+  if (const char* p = getenv("RTMI_PIPELINE")) s->fused_only = std::strcmp(p, "fused") == 0;
   s->dev.n_objects = d->n_objects; s->dev.hit_rule = d->hit_rule; s->dev.stack_entries = stack_entries;
   s->dev.n_spectra = uint32_t(spectra.size() / RT_NBINS);
   s->dev.lds_nodes = stage ? uint32_t(nodes.size()) : 0;
   s->info.n_nodes = uint32_t(nodes.size()); s->info.max_depth = max_depth;
   s->info.n_mesh_triangles = uint32_t(mesh_tris.size()); s->info.n_spectra = s->dev.n_spectra;
-  s->info.node_bytes = nodes.size() * sizeof(BvhNode); s->info.triangle_bytes = mesh_tris.size() * (sizeof(DevMeshTri) + sizeof(DevTriFilter));
+  s->info.node_bytes = nodes.size() * sizeof(BvhNode); s->info.triangle_bytes = mesh_tris.size() * sizeof(DevMeshTri) + mesh_filters.size() * sizeof(DevTriFilter);
   *out = s.release();
   return RTMI_OK;
 }
@@ -485,7 +530,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
 extern "C" void rtmi_scene_destroy(rtmi_scene* s) {
   if (!s) return;
   if (s->ctx) { (void)hipSetDevice(s->ctx->device); (void)hipDeviceSynchronize(); }
-  for (DevBuf* b : {&s->objects, &s->spheres, &s->top_tris, &s->nodes, &s->mesh_tris, &s->mesh_filters, &s->materials, &s->spectra})
+  for (DevBuf* b : {&s->objects, &s->spheres, &s->top_tris, &s->nodes, &s->mesh_tris, &s->mesh_filters, &s->materials, &s->spectra, &s->mesh_objects})
     b->release();
   delete s;
 }
@@ -619,7 +664,9 @@ extern "C" int rtmi_render_accumulate(rtmi_scene* s, const rtmi_camera* cam, con
   const uint32_t samples_per_batch = uint32_t(std::min<uint64_t>(n_samples, std::max<uint64_t>(1, cap / (tiles_per_batch * per_tile))));
   const size_t batch_paths = size_t(tiles_per_batch) * per_tile * samples_per_batch;
   const bool deep = p->integrator == RTMI_INT_RANDOM_WALK && p->max_depth > 16;
-  if (int rc = ensure_workspace(ctx, batch_paths, deep, p->integrator == RTMI_INT_RANDOM_WALK && p->max_depth > 1)) return rc;
+  // the fused kernel needs queues only when paths can continue; the two-kernel pipeline keeps even primary rays in one
+  const bool two_kernel = s->dev.n_meshes > 0 && !s->fused_only;
+  if (int rc = ensure_workspace(ctx, batch_paths, deep, two_kernel || (p->integrator == RTMI_INT_RANDOM_WALK && p->max_depth > 1))) return rc;
   if (int rc = ctx->tiles.reserve(tiles.size() * sizeof(uint32_t))) return rc;
   HIP_TRY(hipMemcpyAsync(ctx->tiles.p, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipStreamSynchronize(stream));  // `tiles` is about to go out of scope

@@ -14,6 +14,7 @@ run() { # name, rocprof args...
 BENCH_ARGS=("$@")
 run trace --kernel-trace --stats || exit 1
 run pmc_sq --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE || exit 1
+run pmc_lanes --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM || exit 1
 run pmc_fetch --pmc FETCH_SIZE TCC_HIT_sum || exit 1
 run pmc_write --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum || exit 1
 find "$out" -name "*.csv" | head -20
