@@ -147,21 +147,30 @@ __device__ __forceinline__ bool sphere_t(const DevSphere& s, V3 o, V3 d, double&
   return true;
 }
 
-// The ray as the binary32 tests see it: origin relative to the mesh centre, direction and its
-// reciprocal, and delta, a bound on how far the binary32 ray can stray from the binary64 one
-// anywhere inside the mesh (rounding of the origin, 2^-24 |o - c|, plus rounding of the direction
-// over the longest useful distance, 2^-24 (|o - c| + R)). Growing every box by delta keeps the box
-// test conservative; 2^-21 (|o - c| + R) leaves a factor of four to spare.
+// The ray as the binary32 box tests see it: origin relative to an object's centre, direction and
+// its reciprocal, and delta, a bound on how far the binary32 ray can stray from the binary64 one
+// anywhere inside the object's bounding sphere (rounding of the origin, 2^-24 |o - c|, plus rounding
+// of the direction over the longest useful distance, 2^-24 (|o - c| + R)). Growing every box by delta
+// keeps the box test conservative; 2^-21 (|o - c| + R) leaves a factor of four to spare.
+struct RayDir { float dx, dy, dz, ix, iy, iz; };
 struct BoxRay { float ox, oy, oz, dx, dy, dz, ix, iy, iz, delta; };
 
-__device__ __forceinline__ BoxRay make_box_ray(V3 o, V3 d, const DevObject& ob) {
-  BoxRay r;
-  r.ox = float(o.x - ob.center[0]); r.oy = float(o.y - ob.center[1]); r.oz = float(o.z - ob.center[2]);
-  r.delta = 0x1.0p-21f * (fmaxf(fmaxf(fabsf(r.ox), fabsf(r.oy)), fabsf(r.oz)) + float(ob.radius) * 1.0000005f);
+__device__ __forceinline__ RayDir make_ray_dir(V3 d) {
+  RayDir r;
   r.dx = float(d.x); r.dy = float(d.y); r.dz = float(d.z);
   r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
   return r;
 }
+
+__device__ __forceinline__ BoxRay make_box_ray(V3 o, const RayDir& d, const DevObject& ob) {
+  BoxRay r;
+  r.ox = float(o.x - ob.center[0]); r.oy = float(o.y - ob.center[1]); r.oz = float(o.z - ob.center[2]);
+  r.delta = 0x1.0p-21f * (fmaxf(fmaxf(fabsf(r.ox), fabsf(r.oy)), fabsf(r.oz)) + float(ob.radius) * 1.0000005f);
+  r.dx = d.dx; r.dy = d.dy; r.dz = d.dz; r.ix = d.ix; r.iy = d.iy; r.iz = d.iz;
+  return r;
+}
+
+__device__ __forceinline__ BoxRay make_box_ray(V3 o, V3 d, const DevObject& ob) { return make_box_ray(o, make_ray_dir(d), ob); }
 
 // Slab test in binary32 against a box grown by the ray's delta. A zero direction component gives
 // +-inf or NaN; fminf/fmaxf drop a NaN operand, which only makes the test more permissive. The
@@ -174,6 +183,15 @@ __device__ __forceinline__ bool slab32(const float* lo, const float* hi, const B
   const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
   tnear = tn;
   return tn <= tf * 1.000002f;
+}
+
+// Can the ray touch the object at all? Every object carries a padded binary32 box around itself
+// (an ellipsoid's, a triangle's or a mesh's extent); a ray that misses it skips the exact binary64
+// test, which for a sphere or a triangle costs five to ten times as much as this.
+__device__ __forceinline__ bool meets_box(const DevObject& ob, V3 o, const RayDir& dir) {
+  const BoxRay br = make_box_ray(o, dir, ob);
+  float tn;
+  return slab32(ob.box_lo, ob.box_hi, br, INFINITY, tn);
 }
 
 #ifdef RT_TRI_FILTER
@@ -334,11 +352,13 @@ __device__ __forceinline__ bool closest_hit(const DevScene& sc, const uint4* __r
   double best_t = 0.0, best_raw = 0.0;
   uint32_t best_obj = 0, best_prim = 0, best_slot = 0;
   const V3 dn = normalize(d);  // what `identity.inverse() * ray` leaves of the direction (src/geometry/ray.rs:45)
+  const RayDir dir = make_ray_dir(dn);
   for (uint32_t i = 0; i < sc.n_objects; ++i) {
     const DevObject ob = sc.objects[i];
     double t, t_raw = 0.0;
     uint32_t prim = 0, slot = 0;
     bool ok;
+    if (ob.kind != RT_OBJ_MODEL && !meets_box(ob, o, dir)) continue;
     if (ob.kind == RT_OBJ_SPHERE) {
       ok = sphere_t(sc.spheres[ob.first], o, d, t);
     } else if (ob.kind == RT_OBJ_TRIANGLE) {
@@ -368,19 +388,19 @@ struct Prelim { double t, t_raw; uint32_t obj; };
 __device__ __forceinline__ bool simple_objects(const DevScene& sc, V3 o, V3 d, V3 dn, Prelim& best) {
   best.t = 0.0; best.t_raw = 0.0; best.obj = RT_MISS;
   bool meets_mesh = false;
+  const RayDir dir = make_ray_dir(dn);
   for (uint32_t i = 0; i < sc.n_objects; ++i) {
     const DevObject ob = sc.objects[i];
     double t, t_raw = 0.0;
     bool ok;
+    if (!meets_box(ob, o, dir)) continue;
     if (ob.kind == RT_OBJ_SPHERE) {
       ok = sphere_t(sc.spheres[ob.first], o, d, t);
     } else if (ob.kind == RT_OBJ_TRIANGLE) {
       const DevTopTri& tr = sc.top_tris[ob.first];
       ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, t_raw, t);
     } else {
-      const BoxRay br = make_box_ray(o, dn, ob);
-      float tn;
-      meets_mesh = meets_mesh || slab32(ob.box_lo, ob.box_hi, br, INFINITY, tn);
+      meets_mesh = true;
       continue;
     }
     if (ok && (best.obj == RT_MISS || t < best.t)) { best.t = t; best.t_raw = t_raw; best.obj = i; }
@@ -843,8 +863,14 @@ shade_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict_
 // of the share, so a wave keeps working at near-full width while some of its rays take ten times
 // as many steps as others. Lanes are serviced (retired, moved to the next mesh, refilled) in groups
 // of at least kRefillLanes to keep that bookkeeping off the traversal's critical path.
-constexpr uint32_t kRefillLanes = 16;
-constexpr uint32_t kMinWaveShare = 512;   // entries; a smaller share leaves too little to refill from
+#ifndef RT_REFILL_LANES
+#define RT_REFILL_LANES 32
+#endif
+#ifndef RT_MIN_WAVE_SHARE
+#define RT_MIN_WAVE_SHARE 512
+#endif
+constexpr uint32_t kRefillLanes = RT_REFILL_LANES;
+constexpr uint32_t kMinWaveShare = RT_MIN_WAVE_SHARE;   // entries; a smaller share leaves too little to refill from
 
 template <int RULE, bool COUNT, bool STAGED>
 __global__ void __launch_bounds__(kBlock) RT_WAVES_ATTR

@@ -34,9 +34,9 @@ struct DevObject {
   uint32_t material;
   uint32_t root;       // models: index of the BVH root node
   uint32_t pad[3];
-  double center[3];    // models: the point the node boxes are relative to
-  double radius;       // models: all triangles lie within this distance of center
-  float box_lo[3];     // models: binary32 box around the whole mesh, relative to center, rounded outward
+  double center[3];    // the point box_lo/box_hi (and a model's node boxes) are relative to
+  double radius;       // the whole object lies within this distance of center
+  float box_lo[3];     // binary32 box around the whole object, relative to center, padded and rounded outward
   float box_hi[3];
   uint32_t pad2[2];
 };

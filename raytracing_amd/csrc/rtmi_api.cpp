@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -173,6 +174,28 @@ bool affine_inverse(const double* m, double* out) {
   out[8] = c02 * id; out[9] = (a01 * a20 - a00 * a21) * id; out[10] = (a00 * a11 - a01 * a10) * id;
   for (int i = 0; i < 3; ++i) out[i * 4 + 3] = -((out[i * 4] * m[3] + out[i * 4 + 1] * m[7]) + out[i * 4 + 2] * m[11]);
   return true;
+}
+
+// Centre, bounding radius and padded binary32 box (relative to the centre, rounded outward) of an object whose
+// extent is [lo, hi]. The pad covers the rounding of the exact binary64 tests, which can accept points a few
+// ulps outside the mathematical surface.
+void set_object_box(DevObject& ob, const double* lo, const double* hi) {
+  double extent = 0.0, r2 = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    ob.center[k] = 0.5 * (lo[k] + hi[k]);
+    const double half = 0.5 * (hi[k] - lo[k]);
+    extent = std::max(extent, half);
+    r2 += half * half;
+  }
+  const double pad = extent * 0x1.0p-20 + 1e-30;
+  ob.radius = (std::sqrt(r2) + pad) * (1.0 + 0x1.0p-20);
+  for (int k = 0; k < 3; ++k) {
+    const double dl = (lo[k] - ob.center[k]) - pad, dh = (hi[k] - ob.center[k]) + pad;
+    float l = float(dl), h = float(dh);
+    if (double(l) > dl) l = std::nextafterf(l, -FLT_MAX);
+    if (double(h) < dh) h = std::nextafterf(h, FLT_MAX);
+    ob.box_lo[k] = l; ob.box_hi[k] = h;
+  }
 }
 
 template <class T>
@@ -442,6 +465,14 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
       if (!affine_inverse(s.l2w, s.w2l)) return fail(RTMI_BAD_ARG, "object %u: sphere transform is singular", i);
       dobj.first = uint32_t(spheres.size());
       spheres.push_back(s);
+      // image of the radius-r sphere under the linear part: half extent along axis k = r * |row k|
+      double lo[3], hi[3];
+      for (int k = 0; k < 3; ++k) {
+        const double* row = s.l2w + 4 * k;
+        const double h = std::fabs(s.radius) * std::sqrt((row[0] * row[0] + row[1] * row[1]) + row[2] * row[2]) * (1.0 + 0x1.0p-40);
+        lo[k] = row[3] - h; hi[k] = row[3] + h;
+      }
+      set_object_box(dobj, lo, hi);
     } else if (o.kind == RTMI_OBJ_TRIANGLE) {
       if (o.first >= d->n_triangles) return fail(RTMI_BAD_ARG, "object %u: triangle %u out of range", i, o.first);
       DevTopTri t{};
@@ -453,6 +484,12 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
       for (int k = 0; k < 3; ++k) t.n[k] = c[k] / len;
       dobj.first = uint32_t(top_tris.size());
       top_tris.push_back(t);
+      double lo[3], hi[3];
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = std::min(v[k], std::min(v[3 + k], v[6 + k]));
+        hi[k] = std::max(v[k], std::max(v[3 + k], v[6 + k]));
+      }
+      set_object_box(dobj, lo, hi);
     } else if (o.kind == RTMI_OBJ_MODEL) {
       if (uint64_t(o.first) + o.count > d->n_triangles) return fail(RTMI_BAD_ARG, "object %u: triangles [%u,+%u) out of range", i, o.first, o.count);
       if (o.count >= (1u << 27)) return fail(RTMI_UNSUPPORTED, "object %u: %u triangles in one mesh", i, o.count);
