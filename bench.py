@@ -20,8 +20,17 @@ ROOT = Path(__file__).resolve().parent
 sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, ~8 TB/s
-STATE_BYTES = 80             # one path-state record: 6 f64 + 4 u32 + 16 chain bytes (read once, written once per bounce)
 NODE_BYTES, TRI_BYTES = 64, 80
+# Algorithmic bytes per unit of the two kernels a roofline is quoted for:
+#   traverse_kernel, per listed ray: list entry (4) + ray origin and direction (48) + the hit record it folds its result
+#     into (12 read, 28 written) + the BVH nodes and triangles that ray visits
+#   bounce_kernel (scenes without meshes), per segment: one path-state record read and one written (6 f64 + 4 u32 + 16
+#     chain bytes each)
+TRAVERSE_RAY_BYTES = 4 + 48 + 12 + 28
+# flops model of the same units: 40 per node visit, 55 per triangle test, 180 + 45 per analytic object for shading
+NODE_FLOPS, TRI_FLOPS, SHADE_FLOPS = 40, 55, 180 + 6 * 45
+VALU_F64_PEAK_TFLOPS = 78.6
+STATE_BYTES = 80
 
 WORKLOADS = {
     # BASELINE.json configs[1]: Suzanne (968 triangles) + emitter + ground spheres, 1920x1080, 64 spp
@@ -115,16 +124,17 @@ def main():
     counted = scene.collect_stats(stream)
     fence()
 
-    kernel_ms, launches, segments = 0.0, 0, 0
+    kernel_ms, launches, segments, trav_ms, trav_launches, mesh_rays = 0.0, 0, 0, 0.0, 0, 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(L.FLAG_TIME_KERNELS)             # HIP events around every closest-hit launch, on `stream`
         st = scene.collect_stats(stream)
         kernel_ms += st["ms_kernels"]; launches += st["launches"]; segments += st["segments"]
+        trav_ms += st["ms_traverse"]; trav_launches += st["traverse_launches"]; mesh_rays += st["mesh_rays"]
     fence()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed, float(segments), kernel_ms, float(launches)], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, float(segments)], dtype=torch.float64, device=device)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -134,17 +144,30 @@ def main():
 
     if rank == 0:
         seg_per_step = counted["segments"]
-        nodes_per_seg = counted["nodes_visited"] / max(1, seg_per_step)
-        tris_per_seg = counted["prims_tested"] / max(1, seg_per_step)
-        bytes_per_seg = 2 * STATE_BYTES + nodes_per_seg * NODE_BYTES + tris_per_seg * TRI_BYTES
-        avg_launch_ms = kernel_ms / max(1, launches)
-        seg_per_launch = segments / max(1, launches)
-        achieved_gbs = (seg_per_launch * bytes_per_seg) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        if trav_launches:       # two-kernel pipeline: the traversal kernel dominates
+            kernel, unit_name = "traverse_kernel", "ray"
+            units = mesh_rays
+            nodes_per_unit = counted["nodes_visited"] / max(1, counted["mesh_rays"])
+            tris_per_unit = counted["prims_tested"] / max(1, counted["mesh_rays"])
+            bytes_per_unit = TRAVERSE_RAY_BYTES + nodes_per_unit * NODE_BYTES + tris_per_unit * TRI_BYTES
+            k_ms, k_launches = trav_ms, trav_launches
+        else:
+            kernel, unit_name = "bounce_kernel", "segment"
+            units = segments
+            nodes_per_unit = counted["nodes_visited"] / max(1, seg_per_step)
+            tris_per_unit = counted["prims_tested"] / max(1, seg_per_step)
+            bytes_per_unit = 2 * STATE_BYTES + nodes_per_unit * NODE_BYTES + tris_per_unit * TRI_BYTES
+            k_ms, k_launches = kernel_ms, launches
+        avg_launch_ms = k_ms / max(1, k_launches)
+        units_per_launch = units / max(1, k_launches)
+        achieved_gbs = (units_per_launch * bytes_per_unit) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        flops_per_unit = nodes_per_unit * NODE_FLOPS + tris_per_unit * TRI_FLOPS + (0 if trav_launches else SHADE_FLOPS)
+        valu_tflops = (units_per_launch * flops_per_unit) / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
         traffic = None
         tfile = ROOT / "profiles" / "hbm_traffic.json"
-        if tfile.exists():
+        if tfile.exists():   # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
             try:
-                traffic = json.loads(tfile.read_text()).get(args.workload, {}).get("bytes_per_launch")
+                traffic = json.loads(tfile.read_text()).get(args.workload, {}).get(kernel, {}).get("bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -164,13 +187,17 @@ def main():
                        "segments_per_step_per_gpu": seg_per_step},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "bounce_kernel", "launches": launches, "avg_launch_ms": avg_launch_ms,
-                         "bytes_per_segment": bytes_per_seg, "nodes_per_segment": nodes_per_seg,
-                         "triangles_per_segment": tris_per_seg, "segments_per_launch": seg_per_launch},
+                         "kernel": kernel, "launches": k_launches, "avg_launch_ms": avg_launch_ms,
+                         "unit_of_work": unit_name, "bytes_per_unit": bytes_per_unit, "nodes_per_unit": nodes_per_unit,
+                         "triangles_per_unit": tris_per_unit, "units_per_launch": units_per_launch,
+                         "all_kernels_ms_per_step": kernel_ms / args.steps, "all_launches": launches,
+                         # the other term of the model: FP64-equivalent vector flops of the same launches
+                         "valu": {"flops_per_unit": flops_per_unit, "achieved": valu_tflops, "peak": VALU_F64_PEAK_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": valu_tflops / VALU_F64_PEAK_TFLOPS}},
         }
         if not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
-            cpu_spp = args.cpu_spp or (1 if w["recipe"] == "synthetic_mesh_scene" else max(1, min(spp, 4)))
+            cpu_spp = args.cpu_spp or (1 if w["recipe"] == "synthetic_mesh_scene" else max(1, min(spp, 16)))
             if w["recipe"] == "synthetic_mesh_scene":
                 out["cpu_baseline"] = None  # linear scans over 1M triangles: minutes per 1e5 segments; not run by default
             else:

@@ -123,8 +123,12 @@ typedef struct {
   uint64_t prims_tested;   /* with RTMI_FLAG_COUNT_TRAVERSAL: mesh triangles put through Moller-Trumbore */
   double ms_total;         /* host wall time of the call */
   double ms_kernels;       /* with RTMI_FLAG_TIME_KERNELS: device time summed over closest-hit kernel launches */
-  uint32_t launches;       /* closest-hit kernel launches */
+  uint32_t launches;       /* closest-hit kernel launches (bounce, or shade + traverse) */
   uint32_t batches;
+  uint64_t mesh_rays;      /* rays handed to the BVH traversal kernel (two-kernel pipeline only) */
+  double ms_traverse;      /* with RTMI_FLAG_TIME_KERNELS: the part of ms_kernels spent in traversal launches */
+  uint32_t traverse_launches;
+  uint32_t reserved;
 } rtmi_stats;
 
 typedef struct {

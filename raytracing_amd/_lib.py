@@ -62,7 +62,8 @@ class RenderParams(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("segments", C.c_uint64), ("paths", C.c_uint64), ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64),
-                ("ms_total", C.c_double), ("ms_kernels", C.c_double), ("launches", C.c_uint32), ("batches", C.c_uint32)]
+                ("ms_total", C.c_double), ("ms_kernels", C.c_double), ("launches", C.c_uint32), ("batches", C.c_uint32),
+                ("mesh_rays", C.c_uint64), ("ms_traverse", C.c_double), ("traverse_launches", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class SceneInfo(C.Structure):

@@ -62,7 +62,7 @@ struct DevBuf {
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
-struct DeviceStats { unsigned long long bounce_segments; TraversalCounters trav; };
+struct DeviceStats { unsigned long long bounce_segments; TraversalCounters trav; unsigned long long mesh_rays; };
 
 }  // namespace
 
@@ -212,25 +212,30 @@ struct Timer {
 
 // HIP-event bracket around closest-hit launches (RTMI_FLAG_TIME_KERNELS)
 struct KernelClock {
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+  struct Span { hipEvent_t a, b; bool traverse; };
+  std::vector<Span> spans;
   bool on = false;
   hipStream_t stream = nullptr;
-  void begin() {
+  double traverse_ms = 0.0;      // of the spans drained so far
+  uint32_t traverse_launches = 0;
+  void begin(bool traverse = false) {
+    if (traverse) ++traverse_launches;
     if (!on) return;
     hipEvent_t a, b;
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     (void)hipEventRecord(a, stream);
-    spans.emplace_back(a, b);
+    spans.push_back(Span{a, b, traverse});
   }
-  void end() { if (on) (void)hipEventRecord(spans.back().second, stream); }
+  void end() { if (on) (void)hipEventRecord(spans.back().b, stream); }
   double drain() {  // waits for the recorded work
     double total = 0.0;
     for (auto& s : spans) {
-      (void)hipEventSynchronize(s.second);
+      (void)hipEventSynchronize(s.b);
       float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, s.first, s.second);
+      (void)hipEventElapsedTime(&ms, s.a, s.b);
       total += ms;
-      (void)hipEventDestroy(s.first); (void)hipEventDestroy(s.second);
+      if (s.traverse) traverse_ms += ms;
+      (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
     }
     spans.clear();
     return total;
@@ -289,7 +294,7 @@ int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra
     ++launches;
     const uint32_t levels = std::max<uint32_t>(depth, 1);   // albedo / normal integrators: the primary hit only
     for (uint32_t k = 0; k < levels; ++k) {
-      clock.begin();
+      clock.begin(true);
       launch_traverse(sc->dev, ctx->queue[k & 1], mesh_list(k), uint32_t(n_paths), region_entries, counters, stream);
       clock.end();
       clock.begin();
@@ -301,6 +306,7 @@ int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra
   }
   launch_emit(sc->dev, o, deep, uint32_t(n_paths), stream);
   if (depth > 1) launch_sum_counts(level_counts(1), depth - 1, &ds->bounce_segments, stream);
+  if (split) launch_sum_counts(level_counts(mesh_level0), std::max<uint32_t>(depth, 1), &ds->mesh_rays, stream);
   HIP_TRY(hipGetLastError());
   return RTMI_OK;
 }
@@ -612,7 +618,7 @@ extern "C" int rtmi_intersect_batch(rtmi_scene* s, const rtmi_ray* rays, size_t 
     HIP_TRY(hipMemcpy(&h, ds, sizeof h, hipMemcpyDeviceToHost));
     std::memset(stats, 0, sizeof *stats);
     stats->segments = n; stats->paths = n;
-    stats->nodes_visited = h.trav.nodes; stats->prims_tested = h.trav.prims;
+    stats->nodes_visited = h.trav.nodes; stats->prims_tested = h.trav.prims; stats->mesh_rays = h.mesh_rays;
     stats->ms_total = timer.ms();
   }
   return RTMI_OK;
@@ -733,6 +739,7 @@ extern "C" int rtmi_render_accumulate(rtmi_scene* s, const rtmi_camera* cam, con
     }
   }
   s->pending.launches = launches; s->pending.batches = batches; s->pending.ms_kernels = kernel_ms;
+  s->pending.ms_traverse = clock.traverse_ms; s->pending.traverse_launches = clock.traverse_launches;
   s->pending.ms_total = timer.ms();
   if (stats) {
     if (clock.on || s->counting) return rtmi_render_collect_stats(s, stream_, stats);
@@ -750,7 +757,7 @@ extern "C" int rtmi_render_collect_stats(rtmi_scene* s, void* stream_, rtmi_stat
     DeviceStats h;
     HIP_TRY(hipMemcpy(&h, s->ctx->stats.p, sizeof h, hipMemcpyDeviceToHost));
     stats->segments += h.bounce_segments;
-    stats->nodes_visited = h.trav.nodes; stats->prims_tested = h.trav.prims;
+    stats->nodes_visited = h.trav.nodes; stats->prims_tested = h.trav.prims; stats->mesh_rays = h.mesh_rays;
   }
   return RTMI_OK;
 }

@@ -190,17 +190,51 @@ def test_partitions_reproduce_full_render(ctx):
     assert (rgb8.cpu().numpy().reshape(h, w, 3) == direct).all()
 
 
+@pytest.mark.parametrize("rule", [O.HIT_FIRST_INDEX, O.HIT_NEAREST])
+@pytest.mark.parametrize("integrator,depth,spp", [(O.INT_RANDOM_WALK, 10, 6), (O.INT_RANDOM_WALK, 20, 2), (O.INT_RANDOM_WALK, 1, 2),
+                                                  (O.INT_ALBEDO, 0, 2), (O.INT_NORMAL, 0, 2)])
+def test_two_kernel_pipeline_equals_fused_and_oracle(ctx, monkeypatch, rule, integrator, depth, spp):
+    """Scenes with meshes run as shade + traverse kernels; RTMI_PIPELINE=fused (read when a scene is
+    created) forces the one-kernel-per-bounce form. Both must produce the same bits, and the oracle's."""
+    from raytracing_amd import api
+    osc, ocam, _ = S.oracle_scene(S.multi_mesh_scene, hit_rule=rule)
+    ref8, _, ref_lin, ref_st = osc.render(ocam, integrator, depth, spp, seed=6)
+    p = api.render_params(integrator, depth, spp, seed=6)
+    monkeypatch.delenv("RTMI_PIPELINE", raising=False)
+    two, cam, _ = S.library_scene(ctx, S.multi_mesh_scene, hit_rule=rule)
+    monkeypatch.setenv("RTMI_PIPELINE", "fused")
+    fused, _, _ = S.library_scene(ctx, S.multi_mesh_scene, hit_rule=rule)
+    i2, x2, s2 = two.render(cam, p)
+    i1, x1, s1 = fused.render(cam, p)
+    assert s2["launches"] > s1["launches"]          # the two scenes really took different routes
+    assert (x1.view(np.uint32) == x2.view(np.uint32)).all() and (i1 == i2).all()
+    assert s1["segments"] == s2["segments"] and s1["paths"] == s2["paths"] == ref_st.paths
+    assert abs(s2["segments"] - ref_st.segments) <= 1e-4 * ref_st.segments + 2
+    assert (x2 == ref_lin).all(axis=2).mean() >= 0.999
+    assert (i2 == ref8).mean() >= 0.995
+
+
+def test_multi_mesh_hits(ctx):
+    """Closest hit over an object list that interleaves meshes, spheres and lone triangles."""
+    for rule in (O.HIT_FIRST_INDEX, O.HIT_NEAREST):
+        osc, ocam, _ = S.oracle_scene(S.multi_mesh_scene, hit_rule=rule)
+        gsc, _, _ = S.library_scene(ctx, S.multi_mesh_scene, hit_rule=rule)
+        for rays in (S.primary_rays(ocam), S.random_rays(20000, 11, center=(0.5, 0.0, 1.0), radius=5.0)):
+            check_hits(gsc.intersect_batch(rays), osc.intersect_batch(rays), "multi mesh rule %d" % rule)
+
+
 def test_small_batches_equal_large(ctx):
     """The batch size only changes scheduling, never the image."""
     from raytracing_amd import api
     small = api.Context(0, max_batch_paths=4096)
-    a, acam, _ = S.library_scene(ctx, scenes.scene3, width=160, height=90)
-    b, bcam, _ = S.library_scene(small, scenes.scene3, width=160, height=90)
-    p = api.render_params(O.INT_RANDOM_WALK, 10, 5, seed=4)
-    ia, xa, sa = a.render(acam, p)
-    ib, xb, sb = b.render(bcam, p)
-    assert (ia == ib).all() and (xa.view(np.uint32) == xb.view(np.uint32)).all()
-    assert sa["segments"] == sb["segments"] and sb["batches"] > sa["batches"]
+    for recipe in (scenes.scene3, scenes.scene1):      # without meshes (fused kernel) and with one (two-kernel pipeline)
+        a, acam, _ = S.library_scene(ctx, recipe, width=160, height=90)
+        b, bcam, _ = S.library_scene(small, recipe, width=160, height=90)
+        p = api.render_params(O.INT_RANDOM_WALK, 10, 5, seed=4)
+        ia, xa, sa = a.render(acam, p)
+        ib, xb, sb = b.render(bcam, p)
+        assert (ia == ib).all() and (xa.view(np.uint32) == xb.view(np.uint32)).all()
+        assert sa["segments"] == sb["segments"] and sb["batches"] > sa["batches"]
     small.close()
 
 

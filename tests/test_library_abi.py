@@ -40,7 +40,7 @@ def test_struct_layouts(L):
     assert L.MATERIAL_DT.itemsize == 8 + 4 * 60 * 4
     assert C.sizeof(L.Camera) == 15 * 8 + 8
     assert C.sizeof(L.RenderParams) == 48
-    assert C.sizeof(L.Stats) == 56
+    assert C.sizeof(L.Stats) == 80
     assert C.sizeof(L.SceneDesc) == 72
 
 
