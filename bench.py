@@ -39,6 +39,8 @@ WORKLOADS = {
     "scene1_400x225_100spp": dict(recipe="scene1", width=400, height=225, spp=100, depth=10),
     "scene3_720p_100spp": dict(recipe="scene3", width=1280, height=720, spp=100, depth=10),
     "mesh1m_4k_16spp": dict(recipe="synthetic_mesh_scene", width=3840, height=2160, spp=16, depth=10),
+    # scene3's layout with glossy / dielectric extension materials, depth 32 (16 of the configuration's 1024 spp)
+    "scene3_extended_4k_16spp": dict(recipe="scene3_extended", width=3840, height=2160, spp=16, depth=32),
 }
 
 

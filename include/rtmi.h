@@ -37,8 +37,14 @@ typedef enum {
 
 /* enum Shape (src/shapes/shape.rs:34-39); BoxAABB is never built by any loader and is not carried */
 enum { RTMI_OBJ_SPHERE = 0, RTMI_OBJ_TRIANGLE = 1, RTMI_OBJ_MODEL = 2 };
-/* enum Type (src/material.rs:5-9) */
-enum { RTMI_MAT_EMITTER = 0, RTMI_MAT_LAMBERTIAN = 1, RTMI_MAT_SPECULAR = 2 };
+/* enum Type (src/material.rs:5-9). GLOSSY and DIELECTRIC are extensions with no counterpart in the
+ * reference, which parses Ns and Ni (src/material.rs:20-22,49-50) but never reads them:
+ *   GLOSSY      Phong lobe of exponent specular_coefficient about the mirror direction; a sample under the
+ *               surface ends the path; weight = specular colour (1 if absent), like Specular
+ *   DIELECTRIC  smooth interface of index optical_density: reflection with Schlick's probability (the form
+ *               sketched at src/scene.rs:103-107) or on total internal reflection, refraction otherwise;
+ *               weight = specular colour (1 if absent) */
+enum { RTMI_MAT_EMITTER = 0, RTMI_MAT_LAMBERTIAN = 1, RTMI_MAT_SPECULAR = 2, RTMI_MAT_GLOSSY = 3, RTMI_MAT_DIELECTRIC = 4 };
 /* which Option<SampledSpectrum> fields of Material are Some (src/material.rs:15-19) */
 enum { RTMI_HAS_AMBIENT = 1, RTMI_HAS_EMITTED = 2, RTMI_HAS_DIFFUSED = 4, RTMI_HAS_SPECULAR = 8 };
 /* Hit rule inside a mesh. FIRST_INDEX is the reference's behaviour (first triangle in file order
@@ -51,8 +57,7 @@ enum { RTMI_SPEC_REFLECTANCE = 0, RTMI_SPEC_ILLUMINANT = 1 };
 /* rtmi_render_params.flags */
 enum {
   RTMI_FLAG_TIME_KERNELS = 1,    /* bracket every closest-hit kernel with HIP events (adds host syncs) */
-  RTMI_FLAG_COUNT_TRAVERSAL = 2, /* count BVH nodes visited and triangles tested (slower kernel variant) */
-  RTMI_FLAG_NO_REGENERATION = 4  /* one queue chain per batch, no refilling of finished path slots */
+  RTMI_FLAG_COUNT_TRAVERSAL = 2  /* count BVH nodes visited and triangles tested (slower kernel variant) */
 };
 
 /* Ray (src/geometry/ray.rs:5-10): direction must be normalised; max_t is always +inf on this path */
@@ -82,11 +87,13 @@ typedef struct { double l2w[12]; double radius; } rtmi_sphere;
  * (src/scene_config.rs:189, src/shapes/model_obj.rs:54): world-space vertices, winding gives the normal */
 typedef struct { double v[9]; } rtmi_triangle;
 
-/* Material (src/material.rs:12-23); specular_coefficient / optical_density are never read on this path */
+/* Material (src/material.rs:12-23); specular_coefficient / optical_density are read by the two extension types only */
 typedef struct {
   uint32_t type;     /* RTMI_MAT_* */
   uint32_t present;  /* RTMI_HAS_* bits */
   float ambient[RTMI_NBINS], emitted[RTMI_NBINS], diffused[RTMI_NBINS], specular[RTMI_NBINS];
+  float specular_coefficient;  /* Ns (src/material.rs:20) */
+  float optical_density;       /* Ni (src/material.rs:22) */
 } rtmi_material;
 
 typedef struct {

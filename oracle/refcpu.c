@@ -230,6 +230,48 @@ void ref_random_versor_cos_density(const double n[3], double r1, double r2, doub
   v3_to(r, out);
 }
 
+/* Extension (no counterpart in the reference): Phong lobe about `axis`, same basis construction as above. */
+void ref_phong_lobe_direction(const double axis[3], double ns, double r1, double r2, double out[3]) {
+  v3 a = v3_from(axis);
+  double cos_t = pow(r1, 1.0 / (ns + 1.0));
+  double sin_t = sqrt(1.0 - cos_t * cos_t);
+  double phi = 2.0 * M_PI * r2;
+  v3 v = v3_make(cos(phi) * sin_t, sin(phi) * sin_t, cos_t);
+  v3 b1 = fabs(a.x) > 0.9 ? v3_make(0, 1, 0) : v3_make(1, 0, 0);
+  b1 = v3_sub(b1, v3_scale(a, v3_dot(b1, a)));
+  b1 = v3_scale(b1, 1.0 / v3_norm(b1));
+  v3 b2 = v3_cross(a, b1);
+  v3 r = v3_make((b1.x * v.x + b2.x * v.y) + a.x * v.z, (b1.y * v.x + b2.y * v.y) + a.y * v.z,
+                 (b1.z * v.x + b2.z * v.y) + a.z * v.z);
+  v3_to(r, out);
+}
+
+/* Extension (no counterpart in the reference; the Schlick form is the one sketched at src/scene.rs:103-107). */
+int ref_dielectric_direction(const double d[3], const double nf_[3], int entering, double ni, double u, double out[3]) {
+  v3 i = v3_from(d), nf = v3_from(nf_);
+  if (!(ni > 0.0)) ni = 1.0;
+  double cosi = -v3_dot(i, nf);
+  double eta = entering ? 1.0 / ni : ni;
+  double sin2t = (eta * eta) * (1.0 - cosi * cosi);
+  int reflect;
+  double cost = 0.0;
+  if (sin2t > 1.0) {
+    reflect = 1;                                   /* total internal reflection */
+  } else {
+    cost = sqrt(1.0 - sin2t);
+    double r0 = (1.0 - ni) / (1.0 + ni);
+    r0 = r0 * r0;
+    double c = entering ? cosi : cost;             /* the angle on the vacuum side */
+    double x = 1.0 - c, x2 = x * x;
+    double refl = r0 + (1.0 - r0) * ((x2 * x2) * x);
+    reflect = u < refl;
+  }
+  v3 r = reflect ? v3_add(i, v3_scale(nf, 2.0 * cosi))
+                 : v3_add(v3_scale(i, eta), v3_scale(nf, eta * cosi - cost));
+  v3_to(r, out);
+  return reflect;
+}
+
 /* ---------------------------------------------------------------- shapes */
 
 typedef struct { uint32_t obj, prim; double t; v3 p, n; } hiti;
@@ -630,7 +672,7 @@ static void trace_ray(const ref_scene* s, rayi ray, uint32_t iter, uint32_t max_
 
 /* src/scene.rs:45-131. `iter` is the reference's `iteraciones`; the hit being shaded is the
  * (max_depth - iter)-th of the path, which indexes the Philox counter. */
-static void shade_point(const ref_scene* s, const hiti* hit, rayi incident, uint32_t iter, uint32_t max_depth,
+static void shade_point(const ref_scene* s, const hiti* hit, rayi incident, int entering, uint32_t iter, uint32_t max_depth,
                         path_ctx* ctx, float* out) {
   const ref_material* m = &s->materials[s->objects[hit->obj].material];
   switch (m->type) {
@@ -652,6 +694,33 @@ static void shade_point(const ref_scene* s, const hiti* hit, rayi incident, uint
       }
       return;
     }
+    case REF_MAT_GLOSSY: {                                            /* extension: Phong lobe about the mirror direction */
+      v3 i = incident.d, n = hit->n;
+      rayi mirror = rayi_new(hit->p, v3_sub(i, v3_scale(n, 2.0 * v3_dot(i, n))));
+      double u[2], axis[3], dir[3];
+      ref_uniform_pair(ctx->seed, ctx->pixel, ctx->sample, max_depth - iter, 1, u);
+      v3_to(mirror.d, axis);
+      ref_phong_lobe_direction(axis, (double)m->specular_coefficient, u[0], u[1], dir);
+      v3 dv = v3_from(dir);
+      if (!(v3_dot(dv, n) > 0.0)) { spec_set(out, 0.0f); return; }   /* the lobe dips under the surface: absorbed */
+      rayi next = rayi_new(v3_add(hit->p, v3_scale(n, 1e-10)), dv);
+      trace_ray(s, next, iter - 1, max_depth, ctx, out);
+      if (m->present & REF_HAS_SPECULAR) spec_mul(out, m->specular);
+      return;
+    }
+    case REF_MAT_DIELECTRIC: {                                        /* extension: smooth dielectric, Schlick reflectance */
+      v3 i = incident.d;
+      v3 nf = v3_dot(hit->n, i) > 0.0 ? v3_neg(hit->n) : hit->n;
+      double u[2], d[3], n[3], dir[3];
+      ref_uniform_pair(ctx->seed, ctx->pixel, ctx->sample, max_depth - iter, 1, u);
+      v3_to(i, d); v3_to(nf, n);
+      int reflected = ref_dielectric_direction(d, n, entering, (double)m->optical_density, u[0], dir);
+      v3 origin = reflected ? v3_add(hit->p, v3_scale(nf, 1e-10)) : v3_sub(hit->p, v3_scale(nf, 1e-10));
+      rayi next = rayi_new(origin, v3_from(dir));
+      trace_ray(s, next, iter - 1, max_depth, ctx, out);
+      if (m->present & REF_HAS_SPECULAR) spec_mul(out, m->specular);
+      return;
+    }
     default: {                                                        /* Specular :80-112 */
       v3 i = incident.d, n = hit->n;
       v3 dir = v3_sub(i, v3_scale(n, 2.0 * v3_dot(i, n)));
@@ -670,8 +739,9 @@ static void trace_ray(const ref_scene* s, rayi ray, uint32_t iter, uint32_t max_
   hiti hit;
   ctx->segments += 1;
   if (!scene_hit(s, ray, &hit)) { spec_set(out, 0.0f); return; }
+  const int entering = v3_dot(hit.n, ray.d) < 0.0;                  /* against the outward normal (extension materials) */
   if (v3_dot(hit.n, ray.d) > 0.0) hit.n = v3_neg(hit.n);            /* :30-32 */
-  shade_point(s, &hit, ray, iter, max_depth, ctx, out);
+  shade_point(s, &hit, ray, entering, iter, max_depth, ctx, out);
 }
 
 /* incident_light of the three integrators */
@@ -681,7 +751,7 @@ static void incident_light(const ref_scene* s, uint32_t integrator, rayi ray, ui
   int ok = scene_hit(s, ray, &hit);
   if (integrator == REF_INT_RANDOM_WALK) {                            /* random_walk.rs:49-75 */
     if (!ok || depth == 0) { spec_set(out, 0.0f); return; }
-    shade_point(s, &hit, ray, depth, depth, ctx, out);               /* normal NOT turned: :74 */
+    shade_point(s, &hit, ray, v3_dot(hit.n, ray.d) < 0.0, depth, depth, ctx, out);   /* normal NOT turned: :74 */
   } else if (integrator == REF_INT_ALBEDO) {                          /* albedo.rs:46-71 */
     if (!ok) { spec_set(out, 0.0f); return; }
     const ref_material* m = &s->materials[s->objects[hit.obj].material];

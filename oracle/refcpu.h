@@ -28,7 +28,10 @@ extern "C" {
 #define REF_MISS 0xFFFFFFFFu
 
 enum { REF_OBJ_SPHERE = 0, REF_OBJ_TRIANGLE = 1, REF_OBJ_MODEL = 2 };
-enum { REF_MAT_EMITTER = 0, REF_MAT_LAMBERTIAN = 1, REF_MAT_SPECULAR = 2 };
+/* GLOSSY and DIELECTRIC are extensions: the reference parses Ns and Ni (src/material.rs:20-22,49-50) but no
+ * material type reads them. Their behaviour is defined here, by this restatement, and nothing in the reference
+ * pins it ("parity unpinned"). */
+enum { REF_MAT_EMITTER = 0, REF_MAT_LAMBERTIAN = 1, REF_MAT_SPECULAR = 2, REF_MAT_GLOSSY = 3, REF_MAT_DIELECTRIC = 4 };
 enum { REF_HAS_AMBIENT = 1, REF_HAS_EMITTED = 2, REF_HAS_DIFFUSED = 4, REF_HAS_SPECULAR = 8 };
 enum { REF_HIT_FIRST_INDEX = 0, REF_HIT_NEAREST = 1 };
 enum { REF_INT_RANDOM_WALK = 0, REF_INT_ALBEDO = 1, REF_INT_NORMAL = 2 };
@@ -54,6 +57,8 @@ typedef struct {
   uint32_t type;
   uint32_t present; /* REF_HAS_* bits */
   float ambient[REF_NBINS], emitted[REF_NBINS], diffused[REF_NBINS], specular[REF_NBINS];
+  float specular_coefficient; /* Ns: exponent of the glossy lobe */
+  float optical_density;      /* Ni: refractive index of a dielectric */
 } ref_material;
 
 typedef struct {
@@ -78,6 +83,15 @@ typedef struct {
 typedef struct { uint64_t segments; uint64_t paths; double seconds; uint32_t threads; uint32_t pad; } ref_stats;
 
 typedef struct ref_scene ref_scene;
+
+/* extension BSDFs (no counterpart in the reference)
+ * Phong lobe about the unit vector `axis`: cos(theta) = r1^(1/(ns+1)), phi = 2 pi r2, in the same basis
+ * construction as the cosine sampler. */
+void ref_phong_lobe_direction(const double axis[3], double ns, double r1, double r2, double out[3]);
+/* Smooth dielectric: d = unit incident direction, nf = unit normal facing against d, entering = the ray comes from
+ * outside, u in [0,1) picks reflection (u < Schlick reflectance, or total internal reflection) or refraction.
+ * Returns 1 when the ray is reflected; out = the (unnormalised) new direction. */
+int ref_dielectric_direction(const double d[3], const double nf[3], int entering, double ni, double u, double out[3]);
 
 /* spectrum (src/spectrum/mod.rs) */
 void ref_spectrum_init(void);

@@ -20,12 +20,12 @@ MISS = 0xFFFFFFFF
 MAX_DEPTH = 32
 OK, BAD_ARG, NO_DEVICE, OOM, HIP_ERROR, UNSUPPORTED = 0, -1, -2, -3, -4, -5
 OBJ_SPHERE, OBJ_TRIANGLE, OBJ_MODEL = 0, 1, 2
-MAT_EMITTER, MAT_LAMBERTIAN, MAT_SPECULAR = 0, 1, 2
+MAT_EMITTER, MAT_LAMBERTIAN, MAT_SPECULAR, MAT_GLOSSY, MAT_DIELECTRIC = 0, 1, 2, 3, 4
 HAS_AMBIENT, HAS_EMITTED, HAS_DIFFUSED, HAS_SPECULAR = 1, 2, 4, 8
 HIT_FIRST_INDEX, HIT_NEAREST = 0, 1
 INT_RANDOM_WALK, INT_ALBEDO, INT_NORMAL = 0, 1, 2
 SPEC_REFLECTANCE, SPEC_ILLUMINANT = 0, 1
-FLAG_TIME_KERNELS, FLAG_COUNT_TRAVERSAL, FLAG_NO_REGENERATION = 1, 2, 4
+FLAG_TIME_KERNELS, FLAG_COUNT_TRAVERSAL = 1, 2
 
 # numpy record layouts of the plain C structs
 RAY_DT = np.dtype([("o", "<f8", 3), ("d", "<f8", 3)])
@@ -34,7 +34,8 @@ OBJECT_DT = np.dtype([("kind", "<u4"), ("first", "<u4"), ("count", "<u4"), ("mat
 SPHERE_DT = np.dtype([("l2w", "<f8", 12), ("radius", "<f8")])
 TRIANGLE_DT = np.dtype([("v", "<f8", 9)])
 MATERIAL_DT = np.dtype([("type", "<u4"), ("present", "<u4"), ("ambient", "<f4", NBINS), ("emitted", "<f4", NBINS),
-                        ("diffused", "<f4", NBINS), ("specular", "<f4", NBINS)])
+                        ("diffused", "<f4", NBINS), ("specular", "<f4", NBINS),
+                        ("specular_coefficient", "<f4"), ("optical_density", "<f4")])
 
 
 class SceneDesc(C.Structure):

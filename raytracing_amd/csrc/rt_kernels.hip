@@ -513,6 +513,48 @@ __device__ __forceinline__ V3 cosine_direction(V3 n, double r1, double r2) {
             (b1.z * v.x + b2.z * v.y) + n.z * v.z);
 }
 
+// Extension materials (no counterpart in the reference). Phong lobe about the unit vector `a`:
+// cos(theta) = r1^(1/(ns+1)), phi = 2 pi r2, in the basis construction of the cosine sampler.
+__device__ __forceinline__ V3 phong_lobe_direction(V3 a, double ns, double r1, double r2) {
+  const double cos_t = pow(r1, 1.0 / (ns + 1.0));
+  const double sin_t = sqrt(1.0 - cos_t * cos_t);
+  const double phi = 2.0 * M_PI * r2;
+  double sp, cp;
+  sincos(phi, &sp, &cp);
+  const V3 v = mk(cp * sin_t, sp * sin_t, cos_t);
+  V3 b1 = fabs(a.x) > 0.9 ? mk(0.0, 1.0, 0.0) : mk(1.0, 0.0, 0.0);
+  b1 = b1 - a * dot(b1, a);
+  b1 = b1 * (1.0 / sqrt(dot(b1, b1)));
+  const V3 b2 = cross(a, b1);
+  return mk((b1.x * v.x + b2.x * v.y) + a.x * v.z, (b1.y * v.x + b2.y * v.y) + a.y * v.z,
+            (b1.z * v.x + b2.z * v.y) + a.z * v.z);
+}
+
+// Smooth dielectric of index ni met by unit direction i; nf = unit normal facing against i. u < R
+// (Schlick's reflectance at the vacuum-side angle) or total internal reflection reflects, otherwise
+// the ray refracts. Returns whether it reflected; `out` is not normalised.
+__device__ __forceinline__ bool dielectric_direction(V3 i, V3 nf, bool entering, double ni, double u, V3& out) {
+  if (!(ni > 0.0)) ni = 1.0;
+  const double cosi = -dot(i, nf);
+  const double eta = entering ? 1.0 / ni : ni;
+  const double sin2t = (eta * eta) * (1.0 - cosi * cosi);
+  bool reflect;
+  double cost = 0.0;
+  if (sin2t > 1.0) {
+    reflect = true;
+  } else {
+    cost = sqrt(1.0 - sin2t);
+    double r0 = (1.0 - ni) / (1.0 + ni);
+    r0 = r0 * r0;
+    const double c = entering ? cosi : cost;
+    const double x = 1.0 - c, x2 = x * x;
+    const double refl = r0 + (1.0 - r0) * ((x2 * x2) * x);
+    reflect = u < refl;
+  }
+  out = reflect ? i + nf * (2.0 * cosi) : i * eta + nf * (eta * cosi - cost);
+  return reflect;
+}
+
 // ------------------------------------------------------------------------------- queues
 
 __device__ __forceinline__ void queue_store(const PathQueue& q, uint32_t at, V3 o, V3 d, uint32_t pixel, uint32_t sample,
@@ -640,6 +682,10 @@ struct Shaded {
 
 // first_hit: the path's first intersection keeps its normal as is (src/integrators/random_walk.rs:74);
 // later hits turn it against the ray (src/scene.rs:30-32).
+// EXT: the scene has glossy or dielectric materials (extensions). Their code (a binary64 pow above all) needs
+// some 40 registers more than the reference's three material types, which costs every scene a resident wave
+// per SIMD, so kernels are instantiated with and without it.
+template <bool EXT>
 __device__ __forceinline__ Shaded shade_hit(const DevScene& sc, const BatchDesc& b, const TraceOutputs& o, bool found, Hit& hit,
                                             bool first_hit, PathState& s) {
   Shaded r;
@@ -661,6 +707,7 @@ __device__ __forceinline__ Shaded shade_hit(const DevScene& sc, const BatchDesc&
       normal_sample(hit.n, xyz, spectrum_out);   // un-turned geometric normal (src/integrators/normal.rs:50)
       contributes = true;
     } else if (s.remaining != 0) {               // depth == 0 returns black after intersecting (random_walk.rs:68-70)
+      const bool entering = dot(hit.n, s.d) < 0.0;   // against the outward normal (dielectric only)
       if (!first_hit && dot(hit.n, s.d) > 0.0) hit.n = neg(hit.n);
       const uint32_t hit_index = b.max_depth - s.remaining;
       if (m.type == RT_MAT_EMITTER) {            // src/scene.rs:56-62
@@ -675,6 +722,31 @@ __device__ __forceinline__ Shaded shade_hit(const DevScene& sc, const BatchDesc&
           r.nd = normalize(cosine_direction(hit.n, r1, r2));
           r.no = hit.p + hit.n * 1e-10;
           chain_set(s.chain, hit_index, m.ambient);
+          r.alive = true;
+        }
+      } else if (EXT && m.type == RT_MAT_GLOSSY) {      // extension: Phong lobe about the mirror direction
+        if (s.remaining > 1) {
+          const V3 axis = normalize(s.d - hit.n * (2.0 * dot(s.d, hit.n)));
+          double r1, r2;
+          uniform_pair(b.seed, s.pixel, s.sample, hit_index, 1, r1, r2);
+          const V3 dir = phong_lobe_direction(axis, double(m.ns), r1, r2);
+          if (dot(dir, hit.n) > 0.0) {           // a sample under the surface is absorbed
+            r.nd = normalize(dir);
+            r.no = hit.p + hit.n * 1e-10;
+            chain_set(s.chain, hit_index, (m.present & RT_HAS_SPECULAR) ? uint32_t(m.specular) : uint32_t(RT_NO_SPECTRUM));
+            r.alive = true;
+          }
+        }
+      } else if (EXT && m.type == RT_MAT_DIELECTRIC) {  // extension: smooth dielectric with Schlick's reflectance
+        if (s.remaining > 1) {
+          const V3 nf = dot(hit.n, s.d) > 0.0 ? neg(hit.n) : hit.n;
+          double u0, u1;
+          uniform_pair(b.seed, s.pixel, s.sample, hit_index, 1, u0, u1);
+          V3 dir;
+          const bool reflected = dielectric_direction(s.d, nf, entering, double(m.ni), u0, dir);
+          r.nd = normalize(dir);
+          r.no = reflected ? hit.p + nf * 1e-10 : hit.p - nf * 1e-10;
+          chain_set(s.chain, hit_index, (m.present & RT_HAS_SPECULAR) ? uint32_t(m.specular) : uint32_t(RT_NO_SPECTRUM));
           r.alive = true;
         }
       } else if (s.remaining > 1) {              // Specular, src/scene.rs:80-112
@@ -752,7 +824,7 @@ __device__ __forceinline__ bool queue_position(const uint32_t* s_prefix, const u
 // One bounce for every path of a queue: closest hit, shading, append of the continuing paths.
 // PRIMARY: the path starts here (camera ray from the Philox jitter, or a caller ray); otherwise
 // its state comes from `in`. Used for scenes without meshes, where every lane does the same work.
-template <bool PRIMARY, int RULE, bool COUNT, bool STAGED>
+template <bool PRIMARY, int RULE, bool COUNT, bool EXT>
 __global__ void __launch_bounds__(kBlock) RT_WAVES_ATTR
 bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_counts, uint32_t region_entries,
               PathQueue out, uint32_t* __restrict__ out_counts, TraceOutputs o, TraversalCounters* counters) {
@@ -760,7 +832,7 @@ bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict
   __shared__ uint32_t s_chunk_prefix[kShards + 1];  // chunks of kBlock paths before each input region
   __shared__ uint32_t s_region_fill[kShards];
   uint32_t* stack;
-  const uint4* node_words = stage_nodes<STAGED>(sc, lds_dynamic, stack);
+  const uint4* node_words = stage_nodes<false>(sc, lds_dynamic, stack);
   const bool deep = b.max_depth > 16;
   const uint32_t n_start = b.rays ? b.n_rays : b.n_local_pixels * b.n_samples;
   const uint32_t n_chunks = PRIMARY ? (n_start + kBlock - 1) / kBlock
@@ -784,7 +856,7 @@ bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict
     if (active) {
       Hit hit;
       const bool found = closest_hit<RULE, COUNT>(sc, node_words, ps.o, ps.d, stack, hit, n_nodes, n_prims);
-      sh = shade_hit(sc, b, o, found, hit, PRIMARY, ps);
+      sh = shade_hit<EXT>(sc, b, o, found, hit, PRIMARY, ps);
     }
     append_emit(sc, o, chunk, deep, sh.emits, sh.emit_info, ps.slot, ps.chain);
     const uint32_t at = reserve_in_region(out_counts, region_entries, chunk, sh.alive);
@@ -804,7 +876,7 @@ bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict
 // recorded for the paths of `in` and produces the continuing paths. Either way every path that goes
 // on is appended to `out` with the closest hit of its new ray among spheres and lone triangles, and
 // listed for traverse_kernel if that ray meets the bounding box of a mesh.
-template <bool START>
+template <bool START, bool EXT>
 __global__ void __launch_bounds__(kBlock)
 shade_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_counts, uint32_t region_entries,
              PathQueue out, uint32_t* __restrict__ out_counts, MeshList mesh, TraceOutputs o) {
@@ -840,7 +912,7 @@ shade_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict_
         hit_geometry(sc, sc.objects[hit.obj], ps.o, ps.d, normalize(ps.d), hit.t, in.hit_raw[idx], in.hit_slot[idx], hit.p, hit.n);
       }
       const bool first_hit = b.integrator != RT_INT_RANDOM_WALK || ps.remaining == b.max_depth;
-      sh = shade_hit(sc, b, o, found, hit, first_hit, ps);
+      sh = shade_hit<EXT>(sc, b, o, found, hit, first_hit, ps);
       remaining_next = ps.remaining - 1;
     }
     if (!START) append_emit(sc, o, chunk, deep, sh.emits, sh.emit_info, ps.slot, ps.chain);
@@ -1141,11 +1213,11 @@ inline size_t stack_bytes(const DevScene& sc) {
 
 }  // namespace
 
-// kernel<PRIM, RULE, COUNT, STAGED> chosen from the scene's hit rule, whether traversal counters
-// were asked for, and whether the tree is small enough to live in LDS
+// bounce_kernel<PRIM, RULE, COUNT, EXT> chosen from the scene's hit rule, whether traversal counters were asked
+// for, and whether the scene has extension materials (the fused kernel reads BVH nodes from memory, never LDS)
 #define RTMI_DISPATCH(KERNEL, PRIM, ...)                                                                    \
   do {                                                                                                      \
-    const int sel_ = (sc.hit_rule == RT_HIT_NEAREST ? 4 : 0) | (counters ? 2 : 0) | (sc.lds_nodes ? 1 : 0);  \
+    const int sel_ = (sc.hit_rule == RT_HIT_NEAREST ? 4 : 0) | (counters ? 2 : 0) | (sc.extension_materials ? 1 : 0); \
     switch (sel_) {                                                                                         \
       case 0: hipLaunchKernelGGL((KERNEL<PRIM, 0, false, false>), grid, kBlock, lds, s, __VA_ARGS__); break; \
       case 1: hipLaunchKernelGGL((KERNEL<PRIM, 0, false, true>), grid, kBlock, lds, s, __VA_ARGS__); break;  \
@@ -1163,7 +1235,7 @@ void launch_primary(const DevScene& sc, const BatchDesc& b, PathQueue out, uint3
   const size_t n = b.rays ? size_t(b.n_rays) : size_t(b.n_local_pixels) * b.n_samples;
   if (n == 0) return;
   const dim3 grid(grid_for(n));
-  const size_t lds = stack_bytes(sc);
+  const size_t lds = size_t(sc.stack_entries) * kBlock * sizeof(uint32_t);
   PathQueue none{};
   RTMI_DISPATCH(bounce_kernel, true, sc, b, none, (const uint32_t*)nullptr, region_entries, out, out_counts, o, counters);
 }
@@ -1173,7 +1245,7 @@ void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const u
                    TraversalCounters* counters, hipStream_t s) {
   if (max_in == 0) return;
   const dim3 grid(grid_for(size_t(max_in) + size_t(kShards) * kBlock));
-  const size_t lds = stack_bytes(sc);
+  const size_t lds = size_t(sc.stack_entries) * kBlock * sizeof(uint32_t);
   RTMI_DISPATCH(bounce_kernel, false, sc, b, in, in_counts, region_entries, out, out_counts, o, counters);
 }
 
@@ -1181,15 +1253,18 @@ void launch_generate(const DevScene& sc, const BatchDesc& b, PathQueue out, uint
                      MeshList mesh, hipStream_t s) {
   const size_t n = b.rays ? size_t(b.n_rays) : size_t(b.n_local_pixels) * b.n_samples;
   if (n == 0) return;
-  hipLaunchKernelGGL(shade_kernel<true>, dim3(grid_for(n)), kBlock, 0, s, sc, b, PathQueue{}, (const uint32_t*)nullptr,
+  hipLaunchKernelGGL((shade_kernel<true, false>), dim3(grid_for(n)), kBlock, 0, s, sc, b, PathQueue{}, (const uint32_t*)nullptr,
                      region_entries, out, out_counts, mesh, TraceOutputs{});
 }
 
 void launch_shade(const DevScene& sc, const BatchDesc& b, PathQueue in, const uint32_t* in_counts, uint32_t max_in,
                   PathQueue out, uint32_t* out_counts, uint32_t region_entries, MeshList mesh, TraceOutputs o, hipStream_t s) {
   if (max_in == 0) return;
-  hipLaunchKernelGGL(shade_kernel<false>, dim3(grid_for(size_t(max_in) + size_t(kShards) * kBlock)), kBlock, 0, s, sc, b, in,
-                     in_counts, region_entries, out, out_counts, mesh, o);
+  const dim3 grid(grid_for(size_t(max_in) + size_t(kShards) * kBlock));
+  if (sc.extension_materials)
+    hipLaunchKernelGGL((shade_kernel<false, true>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o);
+  else
+    hipLaunchKernelGGL((shade_kernel<false, false>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o);
 }
 
 void launch_traverse(const DevScene& sc, PathQueue q, MeshList mesh, uint32_t max_in, uint32_t region_entries,

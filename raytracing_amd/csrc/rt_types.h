@@ -22,7 +22,7 @@
 #define RT_NO_SPECTRUM 0xFFu        // chain entry meaning "multiply by 1.0" / absent spectrum
 
 enum { RT_OBJ_SPHERE = 0, RT_OBJ_TRIANGLE = 1, RT_OBJ_MODEL = 2 };
-enum { RT_MAT_EMITTER = 0, RT_MAT_LAMBERTIAN = 1, RT_MAT_SPECULAR = 2 };
+enum { RT_MAT_EMITTER = 0, RT_MAT_LAMBERTIAN = 1, RT_MAT_SPECULAR = 2, RT_MAT_GLOSSY = 3, RT_MAT_DIELECTRIC = 4 };
 enum { RT_HAS_AMBIENT = 1, RT_HAS_EMITTED = 2, RT_HAS_DIFFUSED = 4, RT_HAS_SPECULAR = 8 };
 enum { RT_HIT_FIRST_INDEX = 0, RT_HIT_NEAREST = 1 };
 enum { RT_INT_RANDOM_WALK = 0, RT_INT_ALBEDO = 1, RT_INT_NORMAL = 2 };
@@ -86,6 +86,8 @@ struct DevMaterial {
   uint32_t type;
   uint32_t present;
   uint8_t ambient, emitted, diffused, specular;  // rows of the spectrum table, RT_NO_SPECTRUM if absent
+  float ns;            // exponent of the glossy lobe
+  float ni;            // refractive index of a dielectric
   uint32_t pad;
 };
 
@@ -105,6 +107,7 @@ struct DevScene {
   uint32_t stack_entries;     // LDS traversal stack depth per lane
   uint32_t n_spectra;
   uint32_t lds_nodes;         // > 0: all BVH nodes of the scene (this many) are staged into LDS by every workgroup
+  uint32_t extension_materials;  // some material is glossy or dielectric: kernels with that shading code are used
 };
 
 struct DevCamera {

@@ -431,13 +431,16 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
     return fail(RTMI_BAD_ARG, "a non-empty array is NULL");
 
   std::vector<DevMaterial> mats(d->n_materials);
+  bool extension_materials = false;
   std::vector<float> spectra;
   auto add_row = [&](const float* s) { spectra.insert(spectra.end(), s, s + RT_NBINS); return uint32_t(spectra.size() / RT_NBINS - 1); };
   for (uint32_t i = 0; i < d->n_materials; ++i) {
     const rtmi_material& m = d->materials[i];
-    if (m.type > RTMI_MAT_SPECULAR) return fail(RTMI_UNSUPPORTED, "material %u has unknown type %u", i, m.type);
+    if (m.type > RTMI_MAT_DIELECTRIC) return fail(RTMI_UNSUPPORTED, "material %u has unknown type %u", i, m.type);
     DevMaterial dm{};
     dm.type = m.type; dm.present = m.present & 15u;
+    dm.ns = m.specular_coefficient; dm.ni = m.optical_density;
+    if (m.type == RTMI_MAT_GLOSSY || m.type == RTMI_MAT_DIELECTRIC) extension_materials = true;
     dm.ambient = dm.emitted = dm.diffused = dm.specular = RT_NO_SPECTRUM;
     uint32_t rows[4] = {RT_NO_SPECTRUM, RT_NO_SPECTRUM, RT_NO_SPECTRUM, RT_NO_SPECTRUM};
     if (m.present & RTMI_HAS_AMBIENT) rows[0] = add_row(m.ambient);
@@ -559,6 +562,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   s->dev.materials = s->materials.as<DevMaterial>();
   s->dev.spectra = s->spectra.as<float>();
   s->dev.mesh_objects = s->mesh_objects.as<uint32_t>(); s->dev.n_meshes = uint32_t(mesh_objects.size());
+  s->dev.extension_materials = extension_materials ? 1u : 0u;
   if (const char* p = getenv("RTMI_PIPELINE")) s->fused_only = std::strcmp(p, "fused") == 0;
   s->dev.n_objects = d->n_objects; s->dev.hit_rule = d->hit_rule; s->dev.stack_entries = stack_entries;
   s->dev.n_spectra = uint32_t(spectra.size() / RT_NBINS);

@@ -121,7 +121,15 @@ namespace {
 std::uint32_t add_material(FlatScene& f, const Material& m) {
   rtmi_material r;
   std::memset(&r, 0, sizeof r);
-  r.type = m.tipo == Type::Emitter ? RTMI_MAT_EMITTER : m.tipo == Type::Lambertian ? RTMI_MAT_LAMBERTIAN : RTMI_MAT_SPECULAR;
+  switch (m.tipo) {
+    case Type::Emitter: r.type = RTMI_MAT_EMITTER; break;
+    case Type::Lambertian: r.type = RTMI_MAT_LAMBERTIAN; break;
+    case Type::Specular: r.type = RTMI_MAT_SPECULAR; break;
+    case Type::Glossy: r.type = RTMI_MAT_GLOSSY; break;
+    case Type::Dielectric: r.type = RTMI_MAT_DIELECTRIC; break;
+  }
+  r.specular_coefficient = float(m.specular_coefficient.value_or(0.0));
+  r.optical_density = float(m.optical_density.value_or(1.0));
   auto put = [&](const std::optional<SampledSpectrum>& s, std::uint32_t bit, float* dst) {
     if (!s) return;
     r.present |= bit;

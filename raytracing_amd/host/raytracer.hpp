@@ -56,7 +56,8 @@ struct SampledSpectrum {
   std::array<float, 3> to_RGB() const;                                            // :624-626
 };
 
-enum class Type { Emitter, Lambertian, Specular };               // src/material.rs:5-9
+// src/material.rs:5-9, plus two extension types that finally read Ns / Ni (no counterpart in the reference)
+enum class Type { Emitter, Lambertian, Specular, Glossy, Dielectric };
 
 struct Material {                                                // src/material.rs:12-37
   Type tipo = Type::Emitter;

@@ -196,6 +196,16 @@ Material material_from_toml(const toml::Table& t) {
   if (type && *type == "Lambertian") { m.tipo = Type::Lambertian; m.ambient_color = color; }
   else if (type && *type == "Specular") { m.tipo = Type::Specular; m.specular_color = color; }
   else if (emitter) { m.tipo = Type::Emitter; m.emitted_color = color; }
+  // extensions (no counterpart in the reference): type = "Glossy" with specular_coefficient, "Dielectric" with optical_density
+  else if (type && (*type == "Glossy" || *type == "Dielectric")) {
+    m.tipo = *type == "Glossy" ? Type::Glossy : Type::Dielectric;
+    m.specular_color = color;
+    const char* key = *type == "Glossy" ? "specular_coefficient" : "optical_density";
+    const toml::Value* v = t.get(key);
+    const double* d = v ? v->as_float() : nullptr;
+    if (!d) throw Error(err);
+    if (*type == "Glossy") m.specular_coefficient = *d; else m.optical_density = *d;
+  }
   else throw Error("not yet implemented: material type " + (type ? "\"" + *type + "\"" : std::string("<none>")));  // todo!() :225,244,247
   return m;
 }

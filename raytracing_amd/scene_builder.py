@@ -106,9 +106,10 @@ class SceneBuilder:
         self._tri_blocks, self._n_tris = [], 0
 
     # ---- materials ------------------------------------------------------------------------
-    def _material(self, type_, ambient=None, emitted=None, diffused=None, specular=None):
+    def _material(self, type_, ambient=None, emitted=None, diffused=None, specular=None, ns=0.0, ni=1.0):
         m = np.zeros((), dtype=L.MATERIAL_DT)
         m["type"] = type_
+        m["specular_coefficient"], m["optical_density"] = ns, ni
         for bit, name, spec in ((L.HAS_AMBIENT, "ambient", ambient), (L.HAS_EMITTED, "emitted", emitted),
                                 (L.HAS_DIFFUSED, "diffused", diffused), (L.HAS_SPECULAR, "specular", specular)):
             if spec is not None:
@@ -121,8 +122,13 @@ class SceneBuilder:
         """Material::default(): an Emitter with no colour, i.e. a black absorber (src/material.rs:25-37)."""
         return self._material(L.MAT_EMITTER)
 
-    def material(self, type_, albedo):
-        """Material::from_toml (src/scene_config.rs:197-250); Emitter albedo uses the illuminant basis."""
+    def material(self, type_, albedo, ns=0.0, ni=1.0):
+        """Material::from_toml (src/scene_config.rs:197-250); Emitter albedo uses the illuminant basis.
+        "Glossy" (exponent ns) and "Dielectric" (index ni) are extensions with no counterpart in the reference."""
+        if type_ == "Glossy":
+            return self._material(L.MAT_GLOSSY, specular=self.from_rgb(albedo, L.SPEC_REFLECTANCE), ns=ns)
+        if type_ == "Dielectric":
+            return self._material(L.MAT_DIELECTRIC, specular=self.from_rgb(albedo, L.SPEC_REFLECTANCE), ni=ni)
         if type_ == "Lambertian":
             return self._material(L.MAT_LAMBERTIAN, ambient=self.from_rgb(albedo, L.SPEC_REFLECTANCE))
         if type_ == "Specular":
@@ -131,11 +137,12 @@ class SceneBuilder:
             return self._material(L.MAT_EMITTER, emitted=self.from_rgb(albedo, L.SPEC_ILLUMINANT))
         raise ValueError("unknown material type %r" % (type_,))
 
-    def mtl_material(self, ka, kd, ks, ke=None):
-        """From<&mtl::Material> (src/material.rs:39-53): always Lambertian, ambient = Ka."""
+    def mtl_material(self, ka, kd, ks, ke=None, ns=0.0, ni=None):
+        """From<&mtl::Material> (src/material.rs:39-53): always Lambertian, ambient = Ka; Ns and Ni are carried along
+        (an absent Ni flattens to 1)."""
         refl = lambda c: self.from_rgb(c, L.SPEC_REFLECTANCE)
         return self._material(L.MAT_LAMBERTIAN, ambient=refl(ka), emitted=refl(ke) if ke is not None else None,
-                              diffused=refl(kd), specular=refl(ks))
+                              diffused=refl(kd), specular=refl(ks), ns=ns, ni=1.0 if ni is None else ni)
 
     # ---- shapes, in scene order -----------------------------------------------------------
     def add_sphere(self, center, radius, scale=(1.0, 1.0, 1.0), material=None):

@@ -11,13 +11,13 @@ from .scene_builder import SceneBuilder, load_golden_mesh, procedural_mesh
 
 
 def _cubo_material(b):
-    # cubo.mtl:4-12 -- Ka 1 1 1, Kd .162632 .037185 .010680, Ks .5 .5 .5, Ke 0 0 0 (Ke present)
-    return b.mtl_material((1.0, 1.0, 1.0), (0.162632, 0.037185, 0.010680), (0.5, 0.5, 0.5), (0.0, 0.0, 0.0))
+    # cubo.mtl:4-12 -- Ns 360, Ka 1 1 1, Kd .162632 .037185 .010680, Ks .5 .5 .5, Ke 0 0 0 (Ke present), Ni 1.45
+    return b.mtl_material((1.0, 1.0, 1.0), (0.162632, 0.037185, 0.010680), (0.5, 0.5, 0.5), (0.0, 0.0, 0.0), ns=360.0, ni=1.45)
 
 
 def _mono_material(b):
-    # mono.mtl:4-10 -- Ka = Kd = Ks = 0.8, no Ke
-    return b.mtl_material((0.8, 0.8, 0.8), (0.8, 0.8, 0.8), (0.8, 0.8, 0.8), None)
+    # mono.mtl:4-10 -- Ns 500, Ka = Kd = Ks = 0.8, no Ke, no Ni
+    return b.mtl_material((0.8, 0.8, 0.8), (0.8, 0.8, 0.8), (0.8, 0.8, 0.8), None, ns=500.0)
 
 
 def scene1(from_rgb=None, width=400, height=225, fan="last"):
@@ -53,6 +53,21 @@ def scene3(from_rgb=None, width=1280, height=720):
     b.add_sphere((0.0, 0.0, 1.0), 1.0, material=b.material("Lambertian", (0.8, 0.3, 0.2)))
     for c in ((0.0, 1.3, 0.5), (0.0, -1.3, 0.5), (-1.3, 0.0, 0.5)):
         b.add_sphere(c, 0.5, material=b.material("Specular", (0.8, 0.8, 0.8)))
+    b.add_sphere((0.0, 0.0, -1000.0), 1000.0, material=b.material("Lambertian", (0.208, 0.141, 0.094)))
+    return b, ((-4.5, 0.0, 2.0), 0.1, 120.0, (0.0, 0.5, 0.0), width, height)
+
+
+def scene3_extended(from_rgb=None, width=1280, height=720):
+    """scene3's layout with the materials of its five small spheres cycled through mirror, Lambertian, glossy
+    (Ns 50 and 1000) and dielectric (Ni 1.5). Glossy and dielectric are extensions: no reference counterpart."""
+    b = SceneBuilder(from_rgb)
+    b.add_sphere((0.0, 0.0, 3.0), 1.0, material=b.material("Emitter", (1.0, 1.0, 1.0)))
+    b.add_sphere((0.0, 0.0, 1.0), 1.0, material=b.material("Dielectric", (0.95, 0.95, 0.95), ni=1.5))
+    mats = [b.material("Glossy", (0.8, 0.8, 0.8), ns=50.0), b.material("Glossy", (0.8, 0.6, 0.3), ns=1000.0),
+            b.material("Specular", (0.8, 0.8, 0.8))]
+    for c, m in zip(((0.0, 1.3, 0.5), (0.0, -1.3, 0.5), (-1.3, 0.0, 0.5)), mats):
+        b.add_sphere(c, 0.5, material=m)
+    b.add_sphere((-1.6, 1.1, 0.35), 0.35, material=b.material("Lambertian", (0.2, 0.5, 0.3)))
     b.add_sphere((0.0, 0.0, -1000.0), 1000.0, material=b.material("Lambertian", (0.208, 0.141, 0.094)))
     return b, ((-4.5, 0.0, 2.0), 0.1, 120.0, (0.0, 0.5, 0.0), width, height)
 

@@ -12,7 +12,7 @@ LIB_PATH = ROOT / "oracle" / "librefcpu.so"
 NBINS = 60
 MISS = 0xFFFFFFFF
 OBJ_SPHERE, OBJ_TRIANGLE, OBJ_MODEL = 0, 1, 2
-MAT_EMITTER, MAT_LAMBERTIAN, MAT_SPECULAR = 0, 1, 2
+MAT_EMITTER, MAT_LAMBERTIAN, MAT_SPECULAR, MAT_GLOSSY, MAT_DIELECTRIC = 0, 1, 2, 3, 4
 HAS_AMBIENT, HAS_EMITTED, HAS_DIFFUSED, HAS_SPECULAR = 1, 2, 4, 8
 HIT_FIRST_INDEX, HIT_NEAREST = 0, 1
 INT_RANDOM_WALK, INT_ALBEDO, INT_NORMAL = 0, 1, 2
@@ -25,7 +25,8 @@ OBJECT_DT = np.dtype([("kind", "<u4"), ("first", "<u4"), ("count", "<u4"), ("mat
 SPHERE_DT = np.dtype([("l2w", "<f8", 12), ("radius", "<f8")])
 TRIANGLE_DT = np.dtype([("v", "<f8", 9)])
 MATERIAL_DT = np.dtype([("type", "<u4"), ("present", "<u4"), ("ambient", "<f4", NBINS), ("emitted", "<f4", NBINS),
-                        ("diffused", "<f4", NBINS), ("specular", "<f4", NBINS)])
+                        ("diffused", "<f4", NBINS), ("specular", "<f4", NBINS),
+                        ("specular_coefficient", "<f4"), ("optical_density", "<f4")])
 
 
 class Affine(C.Structure):
@@ -112,6 +113,9 @@ def lib():
     L.ref_intersect_ray_and_triangle.argtypes = [d3, C.POINTER(Ray), d3]
     L.ref_aabb_intersect_ray.argtypes = [d3, d3, C.POINTER(Ray), d3]
     L.ref_random_versor_cos_density.argtypes = [d3, C.c_double, C.c_double, d3]
+    L.ref_phong_lobe_direction.argtypes = [d3, C.c_double, C.c_double, C.c_double, d3]
+    L.ref_dielectric_direction.restype = C.c_int
+    L.ref_dielectric_direction.argtypes = [d3, d3, C.c_int, C.c_double, C.c_double, d3]
     L.ref_sphere_intersect.argtypes = [C.POINTER(Sphere), C.POINTER(Ray), C.POINTER(Hit)]
     L.ref_triangle_intersect.argtypes = [C.POINTER(Triangle), C.POINTER(Affine), C.POINTER(Ray), C.POINTER(Hit)]
     L.ref_sphere_bounds.argtypes = [C.POINTER(Sphere), d3, d3]

@@ -37,7 +37,7 @@ def test_every_declared_symbol_is_exported_and_bound(L):
 def test_struct_layouts(L):
     assert L.RAY_DT.itemsize == 48 and L.HIT_DT.itemsize == 64
     assert L.OBJECT_DT.itemsize == 16 and L.SPHERE_DT.itemsize == 104 and L.TRIANGLE_DT.itemsize == 72
-    assert L.MATERIAL_DT.itemsize == 8 + 4 * 60 * 4
+    assert L.MATERIAL_DT.itemsize == 8 + 4 * 60 * 4 + 8
     assert C.sizeof(L.Camera) == 15 * 8 + 8
     assert C.sizeof(L.RenderParams) == 48
     assert C.sizeof(L.Stats) == 80
