@@ -118,6 +118,12 @@ __device__ __forceinline__ bool moller_trumbore(V3 v0, V3 v1, V3 v2, V3 o, V3 d,
   return true;
 }
 
+// The t the reference reports for a triangle hit at Moller-Trumbore distance t_raw (src/shapes/triangle.rs:30,92).
+__device__ __forceinline__ double reported_t(V3 v0, V3 v1, V3 v2, double t_raw) {
+  const V3 n = normalize(cross(v1 - v0, v2 - v0));
+  return t_raw / sqrt(dot(n, n));
+}
+
 // Triangle::intersect under the identity map every loader uses (src/shapes/triangle.rs:73-97).
 // `dn` is the ray direction after the reference's re-normalisation of the "local" ray
 // (src/geometry/ray.rs:45). Returns Moller-Trumbore's t (for the hit point) and the t the
@@ -125,9 +131,8 @@ __device__ __forceinline__ bool moller_trumbore(V3 v0, V3 v1, V3 v2, V3 o, V3 d,
 __device__ __forceinline__ bool triangle_hit(V3 v0, V3 v1, V3 v2, V3 o, V3 dn, double& t_raw, double& t_reported) {
   double t;
   if (!moller_trumbore(v0, v1, v2, o, dn, t)) return false;
-  const V3 n = normalize(cross(v1 - v0, v2 - v0));
   t_raw = t;
-  t_reported = t / sqrt(dot(n, n));
+  t_reported = reported_t(v0, v1, v2, t);
   return true;
 }
 
@@ -158,7 +163,9 @@ struct BoxRay { float ox, oy, oz, dx, dy, dz, ix, iy, iz, delta; };
 __device__ __forceinline__ RayDir make_ray_dir(V3 d) {
   RayDir r;
   r.dx = float(d.x); r.dy = float(d.y); r.dz = float(d.z);
-  r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+  // hardware reciprocal (1 ulp): both faces of a slab are scaled by the same factor, so the error only
+  // enters the comparison between axes, well inside slab32's slack
+  r.ix = __builtin_amdgcn_rcpf(r.dx); r.iy = __builtin_amdgcn_rcpf(r.dy); r.iz = __builtin_amdgcn_rcpf(r.dz);
   return r;
 }
 
@@ -270,8 +277,8 @@ __device__ __forceinline__ bool mesh_closest(const uint4* __restrict__ nodes, co
       // nearest rule: nothing farther than the best hit so far (rounded up, with the same slack) can win
       const float tmax = RULE == RT_HIT_NEAREST ? __double2float_ru(best.t) * 1.000002f : INFINITY;
       float tn0, tn1;
-      bool h0 = ref0 != RT_REF_NONE && slab32(lo0, hi0, br, tmax, tn0);
-      bool h1 = ref1 != RT_REF_NONE && slab32(lo1, hi1, br, tmax, tn1);
+      bool h0 = slab32(lo0, hi0, br, tmax, tn0) & (ref0 != RT_REF_NONE);   // no branch: empty slots are rare
+      bool h1 = slab32(lo1, hi1, br, tmax, tn1) & (ref1 != RT_REF_NONE);
       if (RULE == RT_HIT_FIRST_INDEX) { h0 = h0 && min0 < best.index; h1 = h1 && min1 < best.index; }
       if (h0 && h1) {
         const bool swap = RULE == RT_HIT_FIRST_INDEX ? (min1 < min0) : (tn1 < tn0);
@@ -990,6 +997,10 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
   for (;;) {
     // ---- service: every lane whose traversal has ended
     if (cur == kDone && entry != RT_MISS) {
+      if (RULE == RT_HIT_FIRST_INDEX && mh.index != RT_MISS) {
+        const double* v = sc.mesh_tris[first_tri + mh.slot].v;
+        mh.t = reported_t(ld3(v), ld3(v + 3), ld3(v + 6), mh.t_raw);
+      }
       // meshes are visited in scene order, so strict '<' keeps the earlier object on a tie
       if (mh.index != RT_MISS && (best_obj == RT_MISS || mh.t < best_t)) {
         best_t = mh.t; best_raw = mh.t_raw; best_obj = sc.mesh_objects[m]; best_prim = mh.index; best_slot = mh.slot;
@@ -1043,8 +1054,8 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
         const uint32_t ref0 = w3.x, ref1 = w3.y, min0 = w3.z, min1 = w3.w;
         const float tmax = RULE == RT_HIT_NEAREST ? __double2float_ru(mh.t) * 1.000002f : INFINITY;
         float tn0, tn1;
-        bool h0 = ref0 != RT_REF_NONE && slab32(lo0, hi0, br, tmax, tn0);
-        bool h1 = ref1 != RT_REF_NONE && slab32(lo1, hi1, br, tmax, tn1);
+        bool h0 = slab32(lo0, hi0, br, tmax, tn0) & (ref0 != RT_REF_NONE);   // no branch: empty slots are rare
+        bool h1 = slab32(lo1, hi1, br, tmax, tn1) & (ref1 != RT_REF_NONE);
         if (RULE == RT_HIT_FIRST_INDEX) { h0 = h0 && min0 < mh.index; h1 = h1 && min1 < mh.index; }
         if (h0 && h1) {
           const bool swap = RULE == RT_HIT_FIRST_INDEX ? (min1 < min0) : (tn1 < tn0);
@@ -1078,11 +1089,14 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
           const double2 a = v[0], b = v[1], c = v[2], e = v[3];
           const double last = tp->v[8];
           double t_raw, t;
-          if (triangle_hit(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), mk(e.x, e.y, last), o, dn, t_raw, t)) {
-            if (RULE == RT_HIT_FIRST_INDEX) {
-              mh.t = t; mh.t_raw = t_raw; mh.index = index; mh.slot = first + i;
+          if (RULE == RT_HIT_FIRST_INDEX) {
+            // the winner is decided by the index alone: its reported t is formed once, when the lane is serviced
+            if (moller_trumbore(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), mk(e.x, e.y, last), o, dn, t_raw)) {
+              mh.t_raw = t_raw; mh.index = index; mh.slot = first + i;
               break;
-            } else if (t < mh.t || (t == mh.t && index < mh.index)) {
+            }
+          } else if (triangle_hit(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), mk(e.x, e.y, last), o, dn, t_raw, t)) {
+            if (t < mh.t || (t == mh.t && index < mh.index)) {
               mh.t = t; mh.t_raw = t_raw; mh.index = index; mh.slot = first + i;
             }
           }
