@@ -38,6 +38,10 @@ def check_hits(gpu, ref, what):
         scale = np.maximum(1.0, np.abs(ref["p"][hit]).max(axis=1))
         assert (np.abs(gpu["p"][hit] - ref["p"][hit]).max(axis=1) / scale).max() <= 1e-9, what
         assert np.abs(gpu["n"][hit] - ref["n"][hit]).max() <= 1e-9, what
+        # the kernels perform the oracle's IEEE operations in the oracle's order: records agree to the bit
+        bits = ((gpu["t"].view(np.uint64) == ref["t"].view(np.uint64)) & (gpu["p"].view(np.uint64) == ref["p"].view(np.uint64)).all(axis=1)
+                & (gpu["n"].view(np.uint64) == ref["n"].view(np.uint64)).all(axis=1))[hit]
+        assert bits.mean() >= 0.9999, "%s: %.6f of hit records bit-identical" % (what, bits.mean())
     return frac
 
 
