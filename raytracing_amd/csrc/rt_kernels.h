@@ -78,7 +78,10 @@ struct TraceOutputs {
   uint32_t emit_region_entries;
 };
 
-struct TraversalCounters { unsigned long long nodes, prims; };
+// nodes, prims: lane-level work. The *_slots fields count 64 per wave-level iteration of the traversal kernel's node
+// loop, triangle loop and service block (and service_lanes the lanes actually serviced), so that
+// nodes / node_slots etc. give the lane occupancy of each phase.
+struct TraversalCounters { unsigned long long nodes, prims, node_slots, prim_slots, service_slots, service_lanes; };
 
 void upload_constants(const SpectrumTables& t);
 

@@ -837,6 +837,12 @@ __device__ __forceinline__ uint32_t reserve_in_region(uint32_t* counts, uint32_t
   return take ? region * region_entries + start + uint32_t(__popcll(mask & ((1ull << lane) - 1ull))) : RT_MISS;
 }
 
+// COUNT builds: adds 64 to `w` once per wave-level execution of the place it is called from
+__device__ __forceinline__ void count_slot(uint32_t& w) {
+  const unsigned long long m = __ballot(true);
+  if (__lane_id() == uint32_t(__ffsll((long long)m)) - 1u) w += 64u;
+}
+
 // chunk -> position of its first entry's lane in the input queue; false for a lane past the fill
 __device__ __forceinline__ bool queue_position(const uint32_t* s_prefix, const uint32_t* s_fill, uint32_t region_entries,
                                                uint32_t chunk, uint32_t& idx) {
@@ -1002,6 +1008,7 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
   constexpr uint32_t kDone = RT_REF_NONE;  // has the leaf bit set, so it also ends the node loop
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t n_nodes = 0, n_prims = 0;
+  uint32_t w_nodes = 0, w_prims = 0, w_service = 0, n_service = 0;   // COUNT only: wave-level iterations per phase
   uint32_t entry = RT_MISS;                // queue entry whose ray this lane is working on
   V3 o = mk(0, 0, 0), dn = mk(1, 0, 0);
   BoxRay br = {};
@@ -1012,10 +1019,12 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
   double best_t = 0.0, best_raw = 0.0;     // best over the meshes done so far
   uint32_t best_obj = RT_MISS, best_prim = 0, best_slot = 0;
   uint32_t cur = kDone;
+  uint32_t leaf_i = 0;                     // next triangle of the leaf the lane is at
   int sp = 0;
 
   for (;;) {
     // ---- service: every lane whose traversal has ended
+    if (COUNT) { count_slot(w_service); if (cur == kDone) ++n_service; }
     if (cur == kDone && entry != RT_MISS) {
       if (RULE == RT_HIT_FIRST_INDEX && mh.index != RT_MISS) {
         const double* v = sc.mesh_tris[first_tri + mh.slot].v;
@@ -1061,50 +1070,55 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
     if (__ballot(entry != RT_MISS) == 0) break;
     const bool refillable = next < end;
 
-    // ---- traverse until enough lanes can be given new work
+    // ---- traverse until enough lanes can be given new work. Every lane with a ray is in one of two states: at an
+    // inner node (needs a box-test step) or at a leaf (needs a triangle test). Each wave-level iteration runs the step
+    // that more lanes are waiting for; the others keep their state. Letting every lane finish its run of nodes before
+    // any leaf was touched left the node step at 27 % lane occupancy and the triangle step at 40 %.
     for (;;) {
-      while (!(cur & RT_LEAF_FLAG)) {
-        const uint4* np = node_words + (size_t(root) + cur) * 4;
-        const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-        if (COUNT) ++n_nodes;
-        const float lo0[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
-        const float hi0[3] = {__uint_as_float(w0.w), __uint_as_float(w1.x), __uint_as_float(w1.y)};
-        const float lo1[3] = {__uint_as_float(w1.z), __uint_as_float(w1.w), __uint_as_float(w2.x)};
-        const float hi1[3] = {__uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w)};
-        const uint32_t ref0 = w3.x, ref1 = w3.y, min0 = w3.z, min1 = w3.w;
-        const float tmax = RULE == RT_HIT_NEAREST ? __double2float_ru(mh.t) * 1.000002f : INFINITY;
-        float tn0, tn1;
-        bool h0 = slab32(lo0, hi0, br, tmax, tn0) & (ref0 != RT_REF_NONE);   // no branch: empty slots are rare
-        bool h1 = slab32(lo1, hi1, br, tmax, tn1) & (ref1 != RT_REF_NONE);
-        if (RULE == RT_HIT_FIRST_INDEX) { h0 = h0 && min0 < mh.index; h1 = h1 && min1 < mh.index; }
-        if (h0 && h1) {
-          const bool swap = RULE == RT_HIT_FIRST_INDEX ? (min1 < min0) : (tn1 < tn0);
-          stack[(sp++) * kBlock] = swap ? ref0 : ref1;
-          cur = swap ? ref1 : ref0;
-        } else if (h0) {
-          cur = ref0;
-        } else if (h1) {
-          cur = ref1;
-        } else {
-          cur = sp ? stack[(--sp) * kBlock] : kDone;
-        }
-      }
-      if (cur != kDone) {
-        const uint32_t first = (cur & ~RT_LEAF_FLAG) >> 4, cnt = cur & 15u;
-        for (uint32_t i = 0; i < cnt; ++i) {
-          const DevMeshTri* tp = sc.mesh_tris + first_tri + first + i;
-#ifdef RT_TRI_FILTER
-          const DevTriFilter f = sc.mesh_filters[first_tri + first + i];
-          const uint32_t index = f.index;
-#else
-          const uint32_t index = tp->index;
-#endif
-          if (RULE == RT_HIT_FIRST_INDEX && index >= mh.index) break;  // a leaf is sorted by index
-          if (COUNT) ++n_prims;
-#ifdef RT_TRI_FILTER
+      const bool walking = !(cur & RT_LEAF_FLAG);
+      const bool at_leaf = !walking && cur != kDone;
+      const uint32_t n_walking = uint32_t(__popcll(__ballot(walking))), n_at_leaf = uint32_t(__popcll(__ballot(at_leaf)));
+      if (n_walking + n_at_leaf == 0) break;
+      const bool serviceable = cur == kDone && (refillable || (entry != RT_MISS && m + 1 < sc.n_meshes));
+      if (uint32_t(__popcll(__ballot(serviceable))) >= kRefillLanes) break;
+      if (n_walking >= n_at_leaf) {
+        if (walking) {
+          if (COUNT) count_slot(w_nodes);
+          const uint4* np = node_words + (size_t(root) + cur) * 4;
+          const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+          if (COUNT) ++n_nodes;
+          const float lo0[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
+          const float hi0[3] = {__uint_as_float(w0.w), __uint_as_float(w1.x), __uint_as_float(w1.y)};
+          const float lo1[3] = {__uint_as_float(w1.z), __uint_as_float(w1.w), __uint_as_float(w2.x)};
+          const float hi1[3] = {__uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w)};
+          const uint32_t ref0 = w3.x, ref1 = w3.y, min0 = w3.z, min1 = w3.w;
           const float tmax = RULE == RT_HIT_NEAREST ? __double2float_ru(mh.t) * 1.000002f : INFINITY;
-          if (!triangle_maybe_hit(f, br, tmax)) continue;
-#endif
+          float tn0, tn1;
+          bool h0 = slab32(lo0, hi0, br, tmax, tn0) & (ref0 != RT_REF_NONE);   // no branch: empty slots are rare
+          bool h1 = slab32(lo1, hi1, br, tmax, tn1) & (ref1 != RT_REF_NONE);
+          if (RULE == RT_HIT_FIRST_INDEX) { h0 = h0 && min0 < mh.index; h1 = h1 && min1 < mh.index; }
+          if (h0 && h1) {
+            const bool swap = RULE == RT_HIT_FIRST_INDEX ? (min1 < min0) : (tn1 < tn0);
+            stack[(sp++) * kBlock] = swap ? ref0 : ref1;
+            cur = swap ? ref1 : ref0;
+          } else if (h0) {
+            cur = ref0;
+          } else if (h1) {
+            cur = ref1;
+          } else {
+            cur = sp ? stack[(--sp) * kBlock] : kDone;
+          }
+          leaf_i = 0;
+        }
+      } else if (at_leaf) {
+        if (COUNT) count_slot(w_prims);
+        const uint32_t first = (cur & ~RT_LEAF_FLAG) >> 4, cnt = cur & 15u;
+        const uint32_t slot = first + leaf_i;
+        const DevMeshTri* tp = sc.mesh_tris + first_tri + slot;
+        const uint32_t index = tp->index;
+        bool leaf_done = RULE == RT_HIT_FIRST_INDEX && index >= mh.index;   // a leaf is sorted by index
+        if (!leaf_done) {
+          if (COUNT) ++n_prims;
           const double2* v = reinterpret_cast<const double2*>(tp->v);
           const double2 a = v[0], b = v[1], c = v[2], e = v[3];
           const double last = tp->v[8];
@@ -1112,28 +1126,32 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
           if (RULE == RT_HIT_FIRST_INDEX) {
             // the winner is decided by the index alone: its reported t is formed once, when the lane is serviced
             if (moller_trumbore(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), mk(e.x, e.y, last), o, dn, t_raw)) {
-              mh.t_raw = t_raw; mh.index = index; mh.slot = first + i;
-              break;
+              mh.t_raw = t_raw; mh.index = index; mh.slot = slot;
+              leaf_done = true;
             }
           } else if (triangle_hit(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), mk(e.x, e.y, last), o, dn, t_raw, t)) {
             if (t < mh.t || (t == mh.t && index < mh.index)) {
-              mh.t = t; mh.t_raw = t_raw; mh.index = index; mh.slot = first + i;
+              mh.t = t; mh.t_raw = t_raw; mh.index = index; mh.slot = slot;
             }
           }
+          leaf_done = leaf_done || ++leaf_i == cnt;
         }
-        cur = sp ? stack[(--sp) * kBlock] : kDone;
+        if (leaf_done) {
+          cur = sp ? stack[(--sp) * kBlock] : kDone;
+          leaf_i = 0;
+        }
       }
-      const bool done = cur == kDone;
-      if (__ballot(!done) == 0) break;
-      const bool serviceable = done && (refillable || (entry != RT_MISS && m + 1 < sc.n_meshes));
-      if (uint32_t(__popcll(__ballot(serviceable))) >= kRefillLanes) break;
     }
   }
 
   if (COUNT) {
-    unsigned long long a = n_nodes, c = n_prims;
-    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); c += __shfl_down(c, off); }
-    if (lane == 0) { atomicAdd(&counters->nodes, a); atomicAdd(&counters->prims, c); }
+    unsigned long long v[6] = {n_nodes, n_prims, w_nodes, w_prims, w_service, n_service};
+    unsigned long long* dst[6] = {&counters->nodes, &counters->prims, &counters->node_slots, &counters->prim_slots,
+                                  &counters->service_slots, &counters->service_lanes};
+    for (int k = 0; k < 6; ++k) {
+      for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+      if (lane == 0) atomicAdd(dst[k], v[k]);
+    }
   }
 }
 

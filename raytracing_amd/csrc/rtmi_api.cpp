@@ -623,6 +623,11 @@ extern "C" int rtmi_intersect_batch(rtmi_scene* s, const rtmi_ray* rays, size_t 
     std::memset(stats, 0, sizeof *stats);
     stats->segments = n; stats->paths = n;
     stats->nodes_visited = h.trav.nodes; stats->prims_tested = h.trav.prims; stats->mesh_rays = h.mesh_rays;
+    if (getenv("RTMI_VERBOSE") && h.trav.node_slots)
+      std::fprintf(stderr, "rtmi: traversal lane occupancy: node loop %.1f %% (%llu steps), triangle loop %.1f %% (%llu tests), "
+                   "service block %.1f %% (%llu lanes)\n", 100.0 * h.trav.nodes / h.trav.node_slots, h.trav.nodes,
+                   100.0 * h.trav.prims / std::max(1ull, h.trav.prim_slots), h.trav.prims,
+                   100.0 * h.trav.service_lanes / std::max(1ull, h.trav.service_slots), h.trav.service_lanes);
     stats->ms_total = timer.ms();
   }
   return RTMI_OK;
@@ -762,6 +767,11 @@ extern "C" int rtmi_render_collect_stats(rtmi_scene* s, void* stream_, rtmi_stat
     HIP_TRY(hipMemcpy(&h, s->ctx->stats.p, sizeof h, hipMemcpyDeviceToHost));
     stats->segments += h.bounce_segments;
     stats->nodes_visited = h.trav.nodes; stats->prims_tested = h.trav.prims; stats->mesh_rays = h.mesh_rays;
+    if (getenv("RTMI_VERBOSE") && h.trav.node_slots)
+      std::fprintf(stderr, "rtmi: traversal lane occupancy: node loop %.1f %% (%llu steps), triangle loop %.1f %% (%llu tests), "
+                   "service block %.1f %% (%llu lanes)\n", 100.0 * h.trav.nodes / h.trav.node_slots, h.trav.nodes,
+                   100.0 * h.trav.prims / std::max(1ull, h.trav.prim_slots), h.trav.prims,
+                   100.0 * h.trav.service_lanes / std::max(1ull, h.trav.service_slots), h.trav.service_lanes);
   }
   return RTMI_OK;
 }
