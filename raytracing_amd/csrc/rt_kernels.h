@@ -17,8 +17,8 @@ struct PathQueue {
   uint32_t* remaining;    // ray casts the path may still make (the reference's `iteraciones`)
   uint4* chain0;          // spectrum-table rows picked up at hits 0..15, one byte each
   uint4* chain1;          // hits 16..31
-  // closest hit of the entry's ray, used by the two-kernel pipeline (shade_kernel writes the best of
-  // the spheres and lone triangles, traverse_kernel folds the meshes in). hit_obj == RT_MISS: no hit.
+  // closest mesh hit of the entry's ray, used by the two-kernel pipeline: cleared when the entry is created,
+  // filled in by traverse_kernel. hit_obj == RT_MISS: no mesh was hit.
   double* hit_t;          // t as the reference reports it (what objects are compared by)
   double* hit_raw;        // triangles: Moller-Trumbore's t along the re-normalised ray (places the hit point)
   uint32_t* hit_obj;
@@ -97,21 +97,24 @@ void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const u
 // Two-kernel pipeline, used when the scene has meshes. BVH traversal lengths differ by an order of
 // magnitude between the rays of one wave (a ray caught inside a closed mesh under the first-index
 // rule visits every box on its line), which left four lanes in five idle in the fused kernel. Here
-//   shade_kernel    (dense, coherent)  shades the hits of queue level k, appends the continuing paths
-//                   to level k+1 together with their closest hit among spheres and lone triangles,
-//                   and lists the entries whose ray meets a mesh's bounding box in `mesh_entries`;
-//   traverse_kernel (persistent waves) walks the BVHs for the listed entries only, each wave
-//                   refilling its idle lanes from its share of the list, and updates the hit records.
-// generate = shade_kernel's first form: level 0 from camera rays (or caller rays).
+//   generate_kernel (dense)            level 0 only: lists the primary rays that meet a mesh's box;
+//   traverse_kernel (persistent waves) walks the BVHs for the listed entries only, each wave refilling
+//                   its idle lanes from its share of the list, and records the mesh hit per entry;
+//   shade_kernel    (dense, coherent)  for every path of level k: exact sphere / lone-triangle tests,
+//                   folded with the recorded mesh hit, shading, append of the continuing paths to level
+//                   k+1, and the listing of those whose new ray meets a mesh's box in `mesh_entries`.
+// Level 0 has no queue: a path is recreated from its index (camera jitter or caller ray).
 struct MeshList {
   uint32_t* entries;   // kShards regions of region_entries path-queue positions, region r fed by chunks c % kShards == r
   uint32_t* counts;    // kShards fill counters, kCountStride apart, zeroed by the caller
 };
-void launch_generate(const DevScene& sc, const BatchDesc& b, PathQueue out, uint32_t* out_counts, uint32_t region_entries,
-                     MeshList mesh, hipStream_t s);
-void launch_shade(const DevScene& sc, const BatchDesc& b, PathQueue in, const uint32_t* in_counts, uint32_t max_in,
+// Rays of level 0 of a camera batch all start at the camera's focus; their entries hold only a direction.
+struct FixedOrigin { double x, y, z; bool fixed; };
+void launch_generate(const DevScene& sc, const BatchDesc& b, PathQueue q, uint32_t region_entries, MeshList mesh, hipStream_t s);
+// start: the paths are level 0 (max_in of them, recreated from their index); otherwise they are read from `in`
+void launch_shade(const DevScene& sc, const BatchDesc& b, bool start, PathQueue in, const uint32_t* in_counts, uint32_t max_in,
                   PathQueue out, uint32_t* out_counts, uint32_t region_entries, MeshList mesh, TraceOutputs o, hipStream_t s);
-void launch_traverse(const DevScene& sc, PathQueue q, MeshList mesh, uint32_t max_in, uint32_t region_entries,
+void launch_traverse(const DevScene& sc, PathQueue q, MeshList mesh, uint32_t max_in, uint32_t region_entries, FixedOrigin origin,
                      TraversalCounters* counters, hipStream_t s);
 // Forms the spectrum / XYZ of every queued emitter hit and writes the path's contribution.
 void launch_emit(const DevScene& sc, TraceOutputs o, bool deep, uint32_t max_entries, hipStream_t s);

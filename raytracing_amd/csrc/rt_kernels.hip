@@ -407,32 +407,34 @@ __device__ __forceinline__ bool closest_hit(const DevScene& sc, const uint4* __r
   return true;
 }
 
-// The same loop restricted to spheres and lone triangles; of a mesh only the bounding box is
-// tested (conservatively, in binary32). Returns whether the ray meets any mesh's box, i.e. whether
-// traverse_kernel still has to look at this ray.
+// The same loop restricted to spheres and lone triangles (meshes are traverse_kernel's business).
 struct Prelim { double t, t_raw; uint32_t obj; };
 
-__device__ __forceinline__ bool simple_objects(const DevScene& sc, V3 o, V3 d, V3 dn, Prelim& best) {
+__device__ __forceinline__ void simple_objects(const DevScene& sc, V3 o, V3 d, V3 dn, Prelim& best) {
   best.t = 0.0; best.t_raw = 0.0; best.obj = RT_MISS;
-  bool meets_mesh = false;
   const RayDir dir = make_ray_dir(dn);
   for (uint32_t i = 0; i < sc.n_objects; ++i) {
     const DevObject ob = sc.objects[i];
     double t, t_raw = 0.0;
     bool ok;
-    if (!meets_box(ob, o, dir)) continue;
+    if (ob.kind == RT_OBJ_MODEL || !meets_box(ob, o, dir)) continue;
     if (ob.kind == RT_OBJ_SPHERE) {
       ok = sphere_t(sc.spheres[ob.first], o, d, t);
-    } else if (ob.kind == RT_OBJ_TRIANGLE) {
+    } else {
       const DevTopTri& tr = sc.top_tris[ob.first];
       ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, t_raw, t);
-    } else {
-      meets_mesh = true;
-      continue;
     }
     if (ok && (best.obj == RT_MISS || t < best.t)) { best.t = t; best.t_raw = t_raw; best.obj = i; }
   }
-  return meets_mesh;
+}
+
+// Does the ray meet the (padded binary32) box of any mesh, i.e. does traverse_kernel have to look at it?
+// `d` need not be exactly normalised: the box test only uses its direction, with margins far above an ulp.
+__device__ __forceinline__ bool meets_any_mesh(const DevScene& sc, V3 o, V3 d) {
+  const RayDir dir = make_ray_dir(d);
+  bool meets = false;
+  for (uint32_t k = 0; k < sc.n_meshes; ++k) meets = meets || meets_box(sc.objects[sc.mesh_objects[k]], o, dir);
+  return meets;
 }
 
 // ------------------------------------------------------------------------------- spectra
@@ -905,10 +907,35 @@ bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict
 
 // ------------------------------------------------------------------------------- the two-kernel pipeline
 
-// Dense half of a bounce. START: creates the batch's paths (level 0). Otherwise: shades the hits
-// recorded for the paths of `in` and produces the continuing paths. Either way every path that goes
-// on is appended to `out` with the closest hit of its new ray among spheres and lone triangles, and
-// listed for traverse_kernel if that ray meets the bounding box of a mesh.
+// Level 0 of a batch needs no queue: path idx can be recreated from idx alone (start_path). This kernel
+// only finds the primary rays that meet a mesh's box, stores their direction (and origin, for caller-supplied
+// rays) at position idx of `q` for traverse_kernel, lists idx, and clears every path's hit record.
+__global__ void __launch_bounds__(kBlock)
+generate_kernel(DevScene sc, BatchDesc b, PathQueue q, uint32_t region_entries, MeshList mesh) {
+  const uint32_t n_start = b.rays ? b.n_rays : b.n_local_pixels * b.n_samples;
+  const uint32_t n_chunks = (n_start + kBlock - 1) / kBlock;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t idx = chunk * kBlock + threadIdx.x;
+    bool meets = false;
+    if (idx < n_start) {
+      q.hit_obj[idx] = RT_MISS;
+      PathState ps;
+      if (start_path(b, idx, ps) && meets_any_mesh(sc, ps.o, ps.d)) {
+        meets = true;
+        q.dx[idx] = ps.d.x; q.dy[idx] = ps.d.y; q.dz[idx] = ps.d.z;
+        if (b.rays) { q.ox[idx] = ps.o.x; q.oy[idx] = ps.o.y; q.oz[idx] = ps.o.z; }
+      }
+    }
+    const uint32_t listed = reserve_in_region(mesh.counts, region_entries, chunk, meets);
+    if (meets) mesh.entries[listed] = idx;
+  }
+}
+
+// Dense half of a bounce, for the paths of level k (START: level 0, recreated from their index; otherwise read
+// from `in`): the exact sphere / lone-triangle tests of the path's ray, folded with what traverse_kernel found
+// in the meshes (smaller reported t wins, the earlier object on a tie -- the order the reference's sequential
+// strict-'<' scan produces), hit point and normal for the winner only, shading, and the append of the
+// continuing paths to `out`. A new ray that meets a mesh's box is listed for the next traverse_kernel.
 template <bool START, bool EXT>
 __global__ void __launch_bounds__(kBlock)
 shade_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_counts, uint32_t region_entries,
@@ -930,33 +957,38 @@ shade_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict_
     ps.chain.a = make_uint4(0, 0, 0, 0); ps.chain.b = make_uint4(0, 0, 0, 0);
     Shaded sh;
     sh.alive = false; sh.emits = false; sh.emit_info = 0; sh.no = ps.o; sh.nd = ps.d;
-    uint32_t remaining_next = 0;
-    if (START) {
-      if (active) active = start_path(b, idx, ps);
-      sh.alive = active; sh.no = ps.o; sh.nd = ps.d;
-      remaining_next = ps.remaining;
-    } else if (active) {
-      load_path(in, idx, deep, ps);
+    if (active) {
+      if (START) active = start_path(b, idx, ps);
+      else load_path(in, idx, deep, ps);
+    }
+    if (active) {
+      const V3 dn = normalize(ps.d);   // src/geometry/ray.rs:45
+      Prelim pre;
+      simple_objects(sc, ps.o, ps.d, dn, pre);
       Hit hit;
-      hit.obj = in.hit_obj[idx];
-      const bool found = hit.obj != RT_MISS;
-      if (found) {
-        hit.t = in.hit_t[idx]; hit.prim = in.hit_prim[idx];
-        hit_geometry(sc, sc.objects[hit.obj], ps.o, ps.d, normalize(ps.d), hit.t, in.hit_raw[idx], in.hit_slot[idx], hit.p, hit.n);
+      hit.obj = pre.obj; hit.prim = 0; hit.t = pre.t;
+      double t_raw = pre.t_raw;
+      uint32_t tri_slot = 0;
+      const uint32_t mesh_obj = sc.n_meshes ? in.hit_obj[idx] : RT_MISS;
+      if (mesh_obj != RT_MISS) {
+        const double mesh_t = in.hit_t[idx];
+        if (pre.obj == RT_MISS || mesh_t < pre.t || (mesh_t == pre.t && mesh_obj < pre.obj)) {
+          hit.obj = mesh_obj; hit.t = mesh_t; hit.prim = in.hit_prim[idx];
+          t_raw = in.hit_raw[idx]; tri_slot = in.hit_slot[idx];
+        }
       }
+      const bool found = hit.obj != RT_MISS;
+      if (found) hit_geometry(sc, sc.objects[hit.obj], ps.o, ps.d, dn, hit.t, t_raw, tri_slot, hit.p, hit.n);
       const bool first_hit = b.integrator != RT_INT_RANDOM_WALK || ps.remaining == b.max_depth;
       sh = shade_hit<EXT>(sc, b, o, found, hit, first_hit, ps);
-      remaining_next = ps.remaining - 1;
     }
-    if (!START) append_emit(sc, o, chunk, deep, sh.emits, sh.emit_info, ps.slot, ps.chain);
+    append_emit(sc, o, chunk, deep, sh.emits, sh.emit_info, ps.slot, ps.chain);
     const uint32_t at = reserve_in_region(out_counts, region_entries, chunk, sh.alive);
     bool meets_mesh = false;
     if (sh.alive) {
-      queue_store(out, at, sh.no, sh.nd, ps.pixel, ps.sample, ps.slot, remaining_next, ps.chain, deep);
-      Prelim pre;
-      meets_mesh = simple_objects(sc, sh.no, sh.nd, normalize(sh.nd), pre);
-      out.hit_t[at] = pre.t; out.hit_raw[at] = pre.t_raw; out.hit_obj[at] = pre.obj;
-      out.hit_prim[at] = 0; out.hit_slot[at] = 0;
+      queue_store(out, at, sh.no, sh.nd, ps.pixel, ps.sample, ps.slot, ps.remaining - 1, ps.chain, deep);
+      out.hit_obj[at] = RT_MISS;
+      meets_mesh = meets_any_mesh(sc, sh.no, sh.nd);
     }
     const uint32_t listed = reserve_in_region(mesh.counts, region_entries, chunk, meets_mesh);
     if (meets_mesh) mesh.entries[listed] = at;
@@ -969,7 +1001,7 @@ shade_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict_
 // as many steps as others. Lanes are serviced (retired, moved to the next mesh, refilled) in groups
 // of at least kRefillLanes to keep that bookkeeping off the traversal's critical path.
 #ifndef RT_REFILL_LANES
-#define RT_REFILL_LANES 32
+#define RT_REFILL_LANES 48
 #endif
 #ifndef RT_MIN_WAVE_SHARE
 #define RT_MIN_WAVE_SHARE 512
@@ -979,7 +1011,7 @@ constexpr uint32_t kMinWaveShare = RT_MIN_WAVE_SHARE;   // entries; a smaller sh
 
 template <int RULE, bool COUNT, bool STAGED>
 __global__ void __launch_bounds__(kBlock) RT_WAVES_ATTR
-traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries, TraversalCounters* counters) {
+traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries, FixedOrigin origin, TraversalCounters* counters) {
   extern __shared__ uint4 lds_dynamic[];
   __shared__ uint32_t s_prefix[kShards + 1];   // list entries before each region
   uint32_t* stack;
@@ -1035,14 +1067,9 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
         best_t = mh.t; best_raw = mh.t_raw; best_obj = sc.mesh_objects[m]; best_prim = mh.index; best_slot = mh.slot;
       }
       if (++m == sc.n_meshes) {
-        if (best_obj != RT_MISS) {
-          // fold into what shade_kernel found among spheres and lone triangles: smaller t wins, the earlier object on a tie
-          const uint32_t pre_obj = q.hit_obj[entry];
-          const double pre_t = q.hit_t[entry];
-          if (pre_obj == RT_MISS || best_t < pre_t || (best_t == pre_t && best_obj < pre_obj)) {
-            q.hit_t[entry] = best_t; q.hit_raw[entry] = best_raw; q.hit_obj[entry] = best_obj;
-            q.hit_prim[entry] = best_prim; q.hit_slot[entry] = best_slot;
-          }
+        if (best_obj != RT_MISS) {   // shade_kernel folds this with the spheres and lone triangles
+          q.hit_t[entry] = best_t; q.hit_raw[entry] = best_raw; q.hit_obj[entry] = best_obj;
+          q.hit_prim[entry] = best_prim; q.hit_slot[entry] = best_slot;
         }
         entry = RT_MISS;
       }
@@ -1053,7 +1080,7 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
       if (entry == RT_MISS && g < end) {
         const uint32_t region = find_region(s_prefix, g);
         entry = mesh.entries[region * region_entries + (g - s_prefix[region])];
-        o = mk(q.ox[entry], q.oy[entry], q.oz[entry]);
+        o = origin.fixed ? mk(origin.x, origin.y, origin.z) : mk(q.ox[entry], q.oy[entry], q.oz[entry]);
         dn = normalize(mk(q.dx[entry], q.dy[entry], q.dz[entry]));  // src/geometry/ray.rs:45
         m = 0; best_obj = RT_MISS;
       }
@@ -1301,25 +1328,26 @@ void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const u
   RTMI_DISPATCH(bounce_kernel, false, sc, b, in, in_counts, region_entries, out, out_counts, o, counters);
 }
 
-void launch_generate(const DevScene& sc, const BatchDesc& b, PathQueue out, uint32_t* out_counts, uint32_t region_entries,
-                     MeshList mesh, hipStream_t s) {
+void launch_generate(const DevScene& sc, const BatchDesc& b, PathQueue q, uint32_t region_entries, MeshList mesh, hipStream_t s) {
   const size_t n = b.rays ? size_t(b.n_rays) : size_t(b.n_local_pixels) * b.n_samples;
   if (n == 0) return;
-  hipLaunchKernelGGL((shade_kernel<true, false>), dim3(grid_for(n)), kBlock, 0, s, sc, b, PathQueue{}, (const uint32_t*)nullptr,
-                     region_entries, out, out_counts, mesh, TraceOutputs{});
+  hipLaunchKernelGGL(generate_kernel, dim3(grid_for(n)), kBlock, 0, s, sc, b, q, region_entries, mesh);
 }
 
-void launch_shade(const DevScene& sc, const BatchDesc& b, PathQueue in, const uint32_t* in_counts, uint32_t max_in,
+void launch_shade(const DevScene& sc, const BatchDesc& b, bool start, PathQueue in, const uint32_t* in_counts, uint32_t max_in,
                   PathQueue out, uint32_t* out_counts, uint32_t region_entries, MeshList mesh, TraceOutputs o, hipStream_t s) {
   if (max_in == 0) return;
-  const dim3 grid(grid_for(size_t(max_in) + size_t(kShards) * kBlock));
-  if (sc.extension_materials)
-    hipLaunchKernelGGL((shade_kernel<false, true>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o);
-  else
-    hipLaunchKernelGGL((shade_kernel<false, false>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o);
+  const dim3 grid(grid_for(size_t(max_in) + (start ? 0 : size_t(kShards) * kBlock)));
+  const int sel = (start ? 2 : 0) | (sc.extension_materials ? 1 : 0);
+  switch (sel) {
+    case 0: hipLaunchKernelGGL((shade_kernel<false, false>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o); break;
+    case 1: hipLaunchKernelGGL((shade_kernel<false, true>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o); break;
+    case 2: hipLaunchKernelGGL((shade_kernel<true, false>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o); break;
+    default: hipLaunchKernelGGL((shade_kernel<true, true>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o); break;
+  }
 }
 
-void launch_traverse(const DevScene& sc, PathQueue q, MeshList mesh, uint32_t max_in, uint32_t region_entries,
+void launch_traverse(const DevScene& sc, PathQueue q, MeshList mesh, uint32_t max_in, uint32_t region_entries, FixedOrigin origin,
                      TraversalCounters* counters, hipStream_t s) {
   if (max_in == 0 || sc.n_meshes == 0) return;
   // enough waves to fill the chip twice over when the list is long, one share of kMinWaveShare entries each when it is short
@@ -1329,14 +1357,14 @@ void launch_traverse(const DevScene& sc, PathQueue q, MeshList mesh, uint32_t ma
   const size_t lds = stack_bytes(sc);
   const int sel = (sc.hit_rule == RT_HIT_NEAREST ? 4 : 0) | (counters ? 2 : 0) | (sc.lds_nodes ? 1 : 0);
   switch (sel) {
-    case 0: hipLaunchKernelGGL((traverse_kernel<0, false, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, counters); break;
-    case 1: hipLaunchKernelGGL((traverse_kernel<0, false, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, counters); break;
-    case 2: hipLaunchKernelGGL((traverse_kernel<0, true, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, counters); break;
-    case 3: hipLaunchKernelGGL((traverse_kernel<0, true, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, counters); break;
-    case 4: hipLaunchKernelGGL((traverse_kernel<1, false, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, counters); break;
-    case 5: hipLaunchKernelGGL((traverse_kernel<1, false, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, counters); break;
-    case 6: hipLaunchKernelGGL((traverse_kernel<1, true, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, counters); break;
-    default: hipLaunchKernelGGL((traverse_kernel<1, true, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, counters); break;
+    case 0: hipLaunchKernelGGL((traverse_kernel<0, false, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, counters); break;
+    case 1: hipLaunchKernelGGL((traverse_kernel<0, false, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, counters); break;
+    case 2: hipLaunchKernelGGL((traverse_kernel<0, true, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, counters); break;
+    case 3: hipLaunchKernelGGL((traverse_kernel<0, true, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, counters); break;
+    case 4: hipLaunchKernelGGL((traverse_kernel<1, false, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, counters); break;
+    case 5: hipLaunchKernelGGL((traverse_kernel<1, false, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, counters); break;
+    case 6: hipLaunchKernelGGL((traverse_kernel<1, true, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, counters); break;
+    default: hipLaunchKernelGGL((traverse_kernel<1, true, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, counters); break;
   }
 }
 

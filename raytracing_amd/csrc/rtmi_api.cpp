@@ -286,19 +286,21 @@ int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra
       ++launches;
     }
   } else {
-    // level k lives in queue[k & 1]; generate fills level 0, then per level: traverse, shade (which fills level k + 1)
+    // level k >= 1 lives in queue[k & 1]; level 0 has no queue (queue[0] only carries the listed primary rays' directions and
+    // the hit records, at the paths' own indices). Per level: traverse, then shade (which fills level k + 1).
     auto mesh_list = [&](size_t k) { return MeshList{ctx->mesh_list.as<uint32_t>(), level_counts(mesh_level0 + k)}; };
     clock.begin();
-    launch_generate(sc->dev, b, ctx->queue[0], level_counts(0), region_entries, mesh_list(0), stream);
+    launch_generate(sc->dev, b, ctx->queue[0], region_entries, mesh_list(0), stream);
     clock.end();
     ++launches;
     const uint32_t levels = std::max<uint32_t>(depth, 1);   // albedo / normal integrators: the primary hit only
     for (uint32_t k = 0; k < levels; ++k) {
+      const FixedOrigin origin{b.cam.focus[0], b.cam.focus[1], b.cam.focus[2], k == 0 && !b.rays};
       clock.begin(true);
-      launch_traverse(sc->dev, ctx->queue[k & 1], mesh_list(k), uint32_t(n_paths), region_entries, counters, stream);
+      launch_traverse(sc->dev, ctx->queue[k & 1], mesh_list(k), uint32_t(n_paths), region_entries, origin, counters, stream);
       clock.end();
       clock.begin();
-      launch_shade(sc->dev, b, ctx->queue[k & 1], level_counts(k), uint32_t(n_paths), ctx->queue[(k + 1) & 1], level_counts(k + 1),
+      launch_shade(sc->dev, b, k == 0, ctx->queue[k & 1], level_counts(k), uint32_t(n_paths), ctx->queue[(k + 1) & 1], level_counts(k + 1),
                    region_entries, mesh_list(k + 1 < levels ? k + 1 : k), o, stream);
       clock.end();
       launches += 2;
