@@ -937,9 +937,9 @@ generate_kernel(DevScene sc, BatchDesc b, PathQueue q, uint32_t region_entries, 
 // strict-'<' scan produces), hit point and normal for the winner only, shading, and the append of the
 // continuing paths to `out`. A new ray that meets a mesh's box is listed for the next traverse_kernel.
 template <bool START, bool EXT>
-__global__ void __launch_bounds__(kBlock)
-shade_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_counts, uint32_t region_entries,
-             PathQueue out, uint32_t* __restrict__ out_counts, MeshList mesh, TraceOutputs o) {
+__device__ __forceinline__ void shade_paths(const DevScene& sc, const BatchDesc& b, const PathQueue& in, const uint32_t* __restrict__ in_counts,
+                                            uint32_t region_entries, const PathQueue& out, uint32_t* __restrict__ out_counts,
+                                            const MeshList& mesh, const TraceOutputs& o) {
   __shared__ uint32_t s_chunk_prefix[kShards + 1];
   __shared__ uint32_t s_region_fill[kShards];
   const bool deep = b.max_depth > 16;
@@ -993,6 +993,22 @@ shade_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict_
     const uint32_t listed = reserve_in_region(mesh.counts, region_entries, chunk, meets_mesh);
     if (meets_mesh) mesh.entries[listed] = at;
   }
+}
+
+// The reference's three material types fit in 128 registers, i.e. four waves per SIMD (measured +4 % over the three
+// the allocator settles for by itself); the variant with the extension materials needs about 170 and is left alone.
+template <bool START>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
+shade_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_counts, uint32_t region_entries,
+             PathQueue out, uint32_t* __restrict__ out_counts, MeshList mesh, TraceOutputs o) {
+  shade_paths<START, false>(sc, b, in, in_counts, region_entries, out, out_counts, mesh, o);
+}
+
+template <bool START>
+__global__ void __launch_bounds__(kBlock)
+shade_extended_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_counts, uint32_t region_entries,
+                      PathQueue out, uint32_t* __restrict__ out_counts, MeshList mesh, TraceOutputs o) {
+  shade_paths<START, true>(sc, b, in, in_counts, region_entries, out, out_counts, mesh, o);
 }
 
 // Sparse half of a bounce: BVH traversal for the listed queue entries, by persistent waves. Each
@@ -1340,10 +1356,10 @@ void launch_shade(const DevScene& sc, const BatchDesc& b, bool start, PathQueue 
   const dim3 grid(grid_for(size_t(max_in) + (start ? 0 : size_t(kShards) * kBlock)));
   const int sel = (start ? 2 : 0) | (sc.extension_materials ? 1 : 0);
   switch (sel) {
-    case 0: hipLaunchKernelGGL((shade_kernel<false, false>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o); break;
-    case 1: hipLaunchKernelGGL((shade_kernel<false, true>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o); break;
-    case 2: hipLaunchKernelGGL((shade_kernel<true, false>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o); break;
-    default: hipLaunchKernelGGL((shade_kernel<true, true>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o); break;
+    case 0: hipLaunchKernelGGL((shade_kernel<false>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o); break;
+    case 1: hipLaunchKernelGGL((shade_extended_kernel<false>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o); break;
+    case 2: hipLaunchKernelGGL((shade_kernel<true>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o); break;
+    default: hipLaunchKernelGGL((shade_extended_kernel<true>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o); break;
   }
 }
 
