@@ -11,6 +11,7 @@
 // Citations are file:line in the reference repository.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 
@@ -1024,10 +1025,15 @@ shade_extended_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __
 #endif
 constexpr uint32_t kRefillLanes = RT_REFILL_LANES;
 constexpr uint32_t kMinWaveShare = RT_MIN_WAVE_SHARE;   // entries; a smaller share leaves too little to refill from
+#ifndef RT_MAX_ROUNDS
+#define RT_MAX_ROUNDS 4
+#endif
+constexpr uint32_t kMaxRounds = RT_MAX_ROUNDS;
 
 template <int RULE, bool COUNT, bool STAGED>
 __global__ void __launch_bounds__(kBlock) RT_WAVES_ATTR
-traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries, FixedOrigin origin, TraversalCounters* counters) {
+traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries, FixedOrigin origin, uint32_t resident_waves,
+                TraversalCounters* counters) {
   extern __shared__ uint4 lds_dynamic[];
   __shared__ uint32_t s_prefix[kShards + 1];   // list entries before each region
   uint32_t* stack;
@@ -1045,9 +1051,13 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
   }
   __syncthreads();
   const uint32_t total = s_prefix[kShards];
-  const uint32_t n_waves = gridDim.x * (kBlock / 64);
+  // The list is cut into whole rounds of the waves the chip holds at once (a partial last round leaves most of the
+  // chip idle while it drains): as many rounds as keep a share at kMinWaveShare entries or more, at most kMaxRounds.
+  uint32_t rounds = total / (resident_waves * kMinWaveShare);
+  rounds = rounds < 1 ? 1 : (rounds > kMaxRounds ? kMaxRounds : rounds);
+  const uint32_t n_waves = resident_waves * rounds;
   uint32_t share = (total + n_waves - 1) / n_waves;
-  share = share < kMinWaveShare ? kMinWaveShare : share;
+  share = share < 64u ? 64u : share;
   share = (share + 63u) & ~63u;
   const uint64_t begin = uint64_t(blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * share;
   uint32_t next = begin < total ? uint32_t(begin) : total;
@@ -1366,21 +1376,23 @@ void launch_shade(const DevScene& sc, const BatchDesc& b, bool start, PathQueue 
 void launch_traverse(const DevScene& sc, PathQueue q, MeshList mesh, uint32_t max_in, uint32_t region_entries, FixedOrigin origin,
                      TraversalCounters* counters, hipStream_t s) {
   if (max_in == 0 || sc.n_meshes == 0) return;
-  // enough waves to fill the chip twice over when the list is long, one share of kMinWaveShare entries each when it is short
-  const size_t waves = (size_t(max_in) + kMinWaveShare - 1) / kMinWaveShare;
-  const size_t blocks = (waves + kBlock / 64 - 1) / (kBlock / 64);
-  const dim3 grid(uint32_t(blocks < 1 ? 1 : (blocks < 2048 ? blocks : 2048)));
+  // the kernel cuts the list into whole rounds of `resident` waves (5 per SIMD at its 96 registers, unless the LDS of
+  // the traversal stacks and staged nodes allows fewer workgroups per CU); launch enough workgroups for the most rounds
   const size_t lds = stack_bytes(sc);
+  const uint32_t blocks_per_cu = uint32_t(std::min<size_t>(5, lds ? (160 * 1024) / (lds + 1024) : 5));
+  const uint32_t resident = 256u * std::max(1u, blocks_per_cu) * (kBlock / 64);
+  const size_t waves = std::min<size_t>((size_t(max_in) + kMinWaveShare - 1) / kMinWaveShare, size_t(resident) * kMaxRounds);
+  const dim3 grid(uint32_t(std::max<size_t>(1, (std::max<size_t>(waves, resident) + kBlock / 64 - 1) / (kBlock / 64))));
   const int sel = (sc.hit_rule == RT_HIT_NEAREST ? 4 : 0) | (counters ? 2 : 0) | (sc.lds_nodes ? 1 : 0);
   switch (sel) {
-    case 0: hipLaunchKernelGGL((traverse_kernel<0, false, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, counters); break;
-    case 1: hipLaunchKernelGGL((traverse_kernel<0, false, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, counters); break;
-    case 2: hipLaunchKernelGGL((traverse_kernel<0, true, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, counters); break;
-    case 3: hipLaunchKernelGGL((traverse_kernel<0, true, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, counters); break;
-    case 4: hipLaunchKernelGGL((traverse_kernel<1, false, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, counters); break;
-    case 5: hipLaunchKernelGGL((traverse_kernel<1, false, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, counters); break;
-    case 6: hipLaunchKernelGGL((traverse_kernel<1, true, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, counters); break;
-    default: hipLaunchKernelGGL((traverse_kernel<1, true, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, counters); break;
+    case 0: hipLaunchKernelGGL((traverse_kernel<0, false, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;
+    case 1: hipLaunchKernelGGL((traverse_kernel<0, false, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;
+    case 2: hipLaunchKernelGGL((traverse_kernel<0, true, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;
+    case 3: hipLaunchKernelGGL((traverse_kernel<0, true, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;
+    case 4: hipLaunchKernelGGL((traverse_kernel<1, false, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;
+    case 5: hipLaunchKernelGGL((traverse_kernel<1, false, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;
+    case 6: hipLaunchKernelGGL((traverse_kernel<1, true, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;
+    default: hipLaunchKernelGGL((traverse_kernel<1, true, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;
   }
 }
 
