@@ -7,23 +7,39 @@
 
 namespace rtmi {
 
-// Path-state queue, structure of arrays (one element per path slot, coalesced per wave).
+// Path-state queue, structure of arrays (one element per path slot, coalesced per wave). The arrays sit one
+// after another in a single allocation, each `entries` elements long, so the struct is a base pointer and a
+// count instead of seventeen pointers: with two queues among a kernel's arguments the pointers alone exceeded
+// the scalar register file and the compiler spilled them into vector registers.
 struct PathQueue {
-  double* ox; double* oy; double* oz;
-  double* dx; double* dy; double* dz;
-  uint32_t* pixel;        // y * width + x : Philox counter word 0
-  uint32_t* sample;       // Philox counter word 1
-  uint32_t* slot;         // where this path's contribution goes
-  uint32_t* remaining;    // ray casts the path may still make (the reference's `iteraciones`)
-  uint4* chain0;          // spectrum-table rows picked up at hits 0..15, one byte each
-  uint4* chain1;          // hits 16..31
+  char* base;
+  uint64_t entries;     // multiple of 64 (keeps every array 256-byte aligned)
+  uint32_t deep;        // chain1 is present (paths longer than 16 hits)
+  uint32_t pad;
+#if defined(__HIPCC__)
+#define RTMI_Q_ARRAY(T, name, offset_bytes_per_entry) \
+  __host__ __device__ __forceinline__ T* name() const { return reinterpret_cast<T*>(base + entries * uint64_t(offset_bytes_per_entry)); }
+#else
+#define RTMI_Q_ARRAY(T, name, offset_bytes_per_entry) \
+  T* name() const { return reinterpret_cast<T*>(base + entries * uint64_t(offset_bytes_per_entry)); }
+#endif
+  RTMI_Q_ARRAY(double, ox, 0) RTMI_Q_ARRAY(double, oy, 8) RTMI_Q_ARRAY(double, oz, 16)
+  RTMI_Q_ARRAY(double, dx, 24) RTMI_Q_ARRAY(double, dy, 32) RTMI_Q_ARRAY(double, dz, 40)
+  RTMI_Q_ARRAY(uint32_t, pixel, 48)       // y * width + x : Philox counter word 0
+  RTMI_Q_ARRAY(uint32_t, sample, 52)      // Philox counter word 1
+  RTMI_Q_ARRAY(uint32_t, slot, 56)        // where this path's contribution goes
+  RTMI_Q_ARRAY(uint32_t, remaining, 60)   // ray casts the path may still make (the reference's `iteraciones`)
   // closest mesh hit of the entry's ray, used by the two-kernel pipeline: cleared when the entry is created,
   // filled in by traverse_kernel. hit_obj == RT_MISS: no mesh was hit.
-  double* hit_t;          // t as the reference reports it (what objects are compared by)
-  double* hit_raw;        // triangles: Moller-Trumbore's t along the re-normalised ray (places the hit point)
-  uint32_t* hit_obj;
-  uint32_t* hit_prim;     // meshes: file-order triangle index
-  uint32_t* hit_slot;     // meshes: position of that triangle in leaf order
+  RTMI_Q_ARRAY(double, hit_t, 64)         // t as the reference reports it (what objects are compared by)
+  RTMI_Q_ARRAY(double, hit_raw, 72)       // Moller-Trumbore's t along the re-normalised ray (places the hit point)
+  RTMI_Q_ARRAY(uint32_t, hit_obj, 80)
+  RTMI_Q_ARRAY(uint32_t, hit_prim, 84)    // file-order triangle index
+  RTMI_Q_ARRAY(uint32_t, hit_slot, 88)    // position of that triangle in leaf order
+  RTMI_Q_ARRAY(uint4, chain0, 92)         // spectrum-table rows picked up at hits 0..15, one byte each (92 E is a multiple of 16: E is one of 64)
+  RTMI_Q_ARRAY(uint4, chain1, 108)        // hits 16..31, only when deep
+#undef RTMI_Q_ARRAY
+  static constexpr uint64_t bytes_per_entry(bool deep_) { return deep_ ? 124 : 108; }
 };
 
 constexpr int kBlock = 256;            // 4 waves of 64

@@ -589,11 +589,11 @@ __device__ __forceinline__ bool dielectric_direction(V3 i, V3 nf, bool entering,
 
 __device__ __forceinline__ void queue_store(const PathQueue& q, uint32_t at, V3 o, V3 d, uint32_t pixel, uint32_t sample,
                                             uint32_t slot, uint32_t remaining, const Chain& chain, bool deep) {
-  q.ox[at] = o.x; q.oy[at] = o.y; q.oz[at] = o.z;
-  q.dx[at] = d.x; q.dy[at] = d.y; q.dz[at] = d.z;
-  q.pixel[at] = pixel; q.sample[at] = sample; q.slot[at] = slot; q.remaining[at] = remaining;
-  q.chain0[at] = chain.a;
-  if (deep) q.chain1[at] = chain.b;
+  q.ox()[at] = o.x; q.oy()[at] = o.y; q.oz()[at] = o.z;
+  q.dx()[at] = d.x; q.dy()[at] = d.y; q.dz()[at] = d.z;
+  q.pixel()[at] = pixel; q.sample()[at] = sample; q.slot()[at] = slot; q.remaining()[at] = remaining;
+  q.chain0()[at] = chain.a;
+  if (deep) q.chain1()[at] = chain.b;
 }
 
 // local pixel of a batch -> image coordinates. Tiles are numbered x-major as the reference
@@ -692,11 +692,11 @@ __device__ __forceinline__ bool start_path(const BatchDesc& b, uint32_t idx, Pat
 }
 
 __device__ __forceinline__ void load_path(const PathQueue& q, uint32_t idx, bool deep, PathState& s) {
-  s.o = mk(q.ox[idx], q.oy[idx], q.oz[idx]);
-  s.d = mk(q.dx[idx], q.dy[idx], q.dz[idx]);
-  s.pixel = q.pixel[idx]; s.sample = q.sample[idx]; s.slot = q.slot[idx]; s.remaining = q.remaining[idx];
-  s.chain.a = q.chain0[idx];
-  s.chain.b = deep ? q.chain1[idx] : make_uint4(0, 0, 0, 0);
+  s.o = mk(q.ox()[idx], q.oy()[idx], q.oz()[idx]);
+  s.d = mk(q.dx()[idx], q.dy()[idx], q.dz()[idx]);
+  s.pixel = q.pixel()[idx]; s.sample = q.sample()[idx]; s.slot = q.slot()[idx]; s.remaining = q.remaining()[idx];
+  s.chain.a = q.chain0()[idx];
+  s.chain.b = deep ? q.chain1()[idx] : make_uint4(0, 0, 0, 0);
 }
 
 // What shading a hit decides.
@@ -919,12 +919,12 @@ generate_kernel(DevScene sc, BatchDesc b, PathQueue q, uint32_t region_entries, 
     const uint32_t idx = chunk * kBlock + threadIdx.x;
     bool meets = false;
     if (idx < n_start) {
-      q.hit_obj[idx] = RT_MISS;
+      q.hit_obj()[idx] = RT_MISS;
       PathState ps;
       if (start_path(b, idx, ps) && meets_any_mesh(sc, ps.o, ps.d)) {
         meets = true;
-        q.dx[idx] = ps.d.x; q.dy[idx] = ps.d.y; q.dz[idx] = ps.d.z;
-        if (b.rays) { q.ox[idx] = ps.o.x; q.oy[idx] = ps.o.y; q.oz[idx] = ps.o.z; }
+        q.dx()[idx] = ps.d.x; q.dy()[idx] = ps.d.y; q.dz()[idx] = ps.d.z;
+        if (b.rays) { q.ox()[idx] = ps.o.x; q.oy()[idx] = ps.o.y; q.oz()[idx] = ps.o.z; }
       }
     }
     const uint32_t listed = reserve_in_region(mesh.counts, region_entries, chunk, meets);
@@ -970,12 +970,12 @@ __device__ __forceinline__ void shade_paths(const DevScene& sc, const BatchDesc&
       hit.obj = pre.obj; hit.prim = 0; hit.t = pre.t;
       double t_raw = pre.t_raw;
       uint32_t tri_slot = 0;
-      const uint32_t mesh_obj = sc.n_meshes ? in.hit_obj[idx] : RT_MISS;
+      const uint32_t mesh_obj = sc.n_meshes ? in.hit_obj()[idx] : RT_MISS;
       if (mesh_obj != RT_MISS) {
-        const double mesh_t = in.hit_t[idx];
+        const double mesh_t = in.hit_t()[idx];
         if (pre.obj == RT_MISS || mesh_t < pre.t || (mesh_t == pre.t && mesh_obj < pre.obj)) {
-          hit.obj = mesh_obj; hit.t = mesh_t; hit.prim = in.hit_prim[idx];
-          t_raw = in.hit_raw[idx]; tri_slot = in.hit_slot[idx];
+          hit.obj = mesh_obj; hit.t = mesh_t; hit.prim = in.hit_prim()[idx];
+          t_raw = in.hit_raw()[idx]; tri_slot = in.hit_slot()[idx];
         }
       }
       const bool found = hit.obj != RT_MISS;
@@ -988,7 +988,7 @@ __device__ __forceinline__ void shade_paths(const DevScene& sc, const BatchDesc&
     bool meets_mesh = false;
     if (sh.alive) {
       queue_store(out, at, sh.no, sh.nd, ps.pixel, ps.sample, ps.slot, ps.remaining - 1, ps.chain, deep);
-      out.hit_obj[at] = RT_MISS;
+      out.hit_obj()[at] = RT_MISS;
       meets_mesh = meets_any_mesh(sc, sh.no, sh.nd);
     }
     const uint32_t listed = reserve_in_region(mesh.counts, region_entries, chunk, meets_mesh);
@@ -1094,8 +1094,8 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
       }
       if (++m == sc.n_meshes) {
         if (best_obj != RT_MISS) {   // shade_kernel folds this with the spheres and lone triangles
-          q.hit_t[entry] = best_t; q.hit_raw[entry] = best_raw; q.hit_obj[entry] = best_obj;
-          q.hit_prim[entry] = best_prim; q.hit_slot[entry] = best_slot;
+          q.hit_t()[entry] = best_t; q.hit_raw()[entry] = best_raw; q.hit_obj()[entry] = best_obj;
+          q.hit_prim()[entry] = best_prim; q.hit_slot()[entry] = best_slot;
         }
         entry = RT_MISS;
       }
@@ -1106,8 +1106,8 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
       if (entry == RT_MISS && g < end) {
         const uint32_t region = find_region(s_prefix, g);
         entry = mesh.entries[region * region_entries + (g - s_prefix[region])];
-        o = origin.fixed ? mk(origin.x, origin.y, origin.z) : mk(q.ox[entry], q.oy[entry], q.oz[entry]);
-        dn = normalize(mk(q.dx[entry], q.dy[entry], q.dz[entry]));  // src/geometry/ray.rs:45
+        o = origin.fixed ? mk(origin.x, origin.y, origin.z) : mk(q.ox()[entry], q.oy()[entry], q.oz()[entry]);
+        dn = normalize(mk(q.dx()[entry], q.dy()[entry], q.dz()[entry]));  // src/geometry/ray.rs:45
         m = 0; best_obj = RT_MISS;
       }
       const uint32_t taken = uint32_t(__popcll(idle));

@@ -105,22 +105,13 @@ int bind(const rtmi_ctx* ctx) {
   return RTMI_OK;
 }
 
-PathQueue carve_queue(void* base, size_t paths, bool deep) {
+PathQueue carve_queue(void* base, size_t entries, bool deep) {
   PathQueue q;
-  char* p = static_cast<char*>(base);
-  auto take = [&](size_t bytes) { void* r = p; p += (bytes + 255) & ~size_t(255); return r; };
-  q.ox = (double*)take(paths * 8); q.oy = (double*)take(paths * 8); q.oz = (double*)take(paths * 8);
-  q.dx = (double*)take(paths * 8); q.dy = (double*)take(paths * 8); q.dz = (double*)take(paths * 8);
-  q.pixel = (uint32_t*)take(paths * 4); q.sample = (uint32_t*)take(paths * 4);
-  q.slot = (uint32_t*)take(paths * 4); q.remaining = (uint32_t*)take(paths * 4);
-  q.chain0 = (uint4*)take(paths * 16);
-  q.chain1 = deep ? (uint4*)take(paths * 16) : nullptr;
-  q.hit_t = (double*)take(paths * 8); q.hit_raw = (double*)take(paths * 8);
-  q.hit_obj = (uint32_t*)take(paths * 4); q.hit_prim = (uint32_t*)take(paths * 4); q.hit_slot = (uint32_t*)take(paths * 4);
+  q.base = static_cast<char*>(base); q.entries = entries; q.deep = deep ? 1u : 0u; q.pad = 0;
   return q;
 }
 
-size_t queue_bytes(size_t entries, bool deep) { return entries * (6 * 8 + 4 * 4 + 16 + (deep ? 16 : 0) + 2 * 8 + 3 * 4) + 17 * 256; }
+size_t queue_bytes(size_t entries, bool deep) { return entries * PathQueue::bytes_per_entry(deep) + 256; }
 constexpr size_t kCountLevelWords = size_t(kShards) * kCountStride;            // uint32 words per queue level
 // fill counters: path-queue levels 0..depth+1, the emit queue, then one mesh list per level
 constexpr size_t kCountLevels = 2 * RT_MAX_DEPTH + 5;
