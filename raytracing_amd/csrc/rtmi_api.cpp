@@ -80,6 +80,11 @@ struct rtmi_ctx {
   uint32_t emit_region_entries = 0;
   size_t emit_paths = 0;
   bool emit_deep = false;
+  bool batch_is_default = true;   // max_batch_paths was not chosen by the caller: it may shrink if memory is short
+  void release_workspace() {
+    for (DevBuf* b : {&queue_mem[0], &queue_mem[1], &contrib, &emit_mem, &mesh_list}) b->release();
+    queue_paths = 0; queue_deep = false; emit_paths = 0; emit_deep = false;
+  }
 };
 
 struct rtmi_scene {
@@ -329,6 +334,7 @@ extern "C" int rtmi_ctx_create(int device_id, uint64_t max_batch_paths, rtmi_ctx
   std::unique_ptr<rtmi_ctx> ctx(new rtmi_ctx);
   ctx->device = dev;
   ctx->max_batch_paths = max_batch_paths ? max_batch_paths : kDefaultBatchPaths;
+  ctx->batch_is_default = max_batch_paths == 0;
   if (ctx->max_batch_paths < 256) ctx->max_batch_paths = 256;
   if (ctx->max_batch_paths > (1ull << 30)) ctx->max_batch_paths = 1ull << 30;
   upload_constants(spectrum_tables());
@@ -342,7 +348,7 @@ extern "C" void rtmi_ctx_destroy(rtmi_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   for (auto& q : ctx->queue_mem) q.release();
-  for (DevBuf* b : {&ctx->contrib, &ctx->counts, &ctx->tiles, &ctx->stats, &ctx->rays, &ctx->hits, &ctx->spectra_out, &ctx->image, &ctx->emit_mem})
+  for (DevBuf* b : {&ctx->contrib, &ctx->counts, &ctx->tiles, &ctx->stats, &ctx->rays, &ctx->hits, &ctx->spectra_out, &ctx->image, &ctx->emit_mem, &ctx->mesh_list})
     b->release();
   delete ctx;
 }
@@ -704,14 +710,25 @@ extern "C" int rtmi_render_accumulate(rtmi_scene* s, const rtmi_camera* cam, con
   if (tiles.empty() || n_samples == 0) { if (stats) *stats = s->pending; return RTMI_OK; }
 
   const uint64_t per_tile = uint64_t(T) * T;
-  const uint64_t cap = std::max<uint64_t>(ctx->max_batch_paths, per_tile);
-  const uint32_t tiles_per_batch = uint32_t(std::min<uint64_t>(tiles.size(), cap / per_tile));
-  const uint32_t samples_per_batch = uint32_t(std::min<uint64_t>(n_samples, std::max<uint64_t>(1, cap / (tiles_per_batch * per_tile))));
-  const size_t batch_paths = size_t(tiles_per_batch) * per_tile * samples_per_batch;
   const bool deep = p->integrator == RTMI_INT_RANDOM_WALK && p->max_depth > 16;
   // the fused kernel needs queues only when paths can continue; the two-kernel pipeline keeps even primary rays in one
   const bool two_kernel = s->dev.n_meshes > 0 && !s->fused_only;
-  if (int rc = ensure_workspace(ctx, batch_paths, deep, two_kernel || (p->integrator == RTMI_INT_RANDOM_WALK && p->max_depth > 1))) return rc;
+  uint32_t tiles_per_batch = 0, samples_per_batch = 0;
+  size_t batch_paths = 0;
+  for (;;) {
+    const uint64_t cap = std::max<uint64_t>(ctx->max_batch_paths, per_tile);
+    tiles_per_batch = uint32_t(std::min<uint64_t>(tiles.size(), cap / per_tile));
+    samples_per_batch = uint32_t(std::min<uint64_t>(n_samples, std::max<uint64_t>(1, cap / (tiles_per_batch * per_tile))));
+    batch_paths = size_t(tiles_per_batch) * per_tile * samples_per_batch;
+    const int rc = ensure_workspace(ctx, batch_paths, deep, two_kernel || (p->integrator == RTMI_INT_RANDOM_WALK && p->max_depth > 1));
+    if (rc == RTMI_OK) break;
+    // The default batch is sized for an otherwise empty 288 GB device. If the workspace does not fit, halve the
+    // batch (the image does not depend on it) rather than fail; a caller-chosen cap is never second-guessed.
+    if (rc != RTMI_OOM || !ctx->batch_is_default || ctx->max_batch_paths <= (1ull << 20)) return rc;
+    (void)hipGetLastError();
+    ctx->release_workspace();
+    ctx->max_batch_paths >>= 1;
+  }
   if (int rc = ctx->tiles.reserve(tiles.size() * sizeof(uint32_t))) return rc;
   HIP_TRY(hipMemcpyAsync(ctx->tiles.p, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipStreamSynchronize(stream));  // `tiles` is about to go out of scope

@@ -227,6 +227,41 @@ def test_multi_mesh_hits(ctx):
             check_hits(gsc.intersect_batch(rays), osc.intersect_batch(rays), "multi mesh rule %d" % rule)
 
 
+def test_degenerate_meshes_through_the_two_kernel_pipeline(ctx):
+    """An empty mesh, a one-triangle mesh and a mesh that is the only light, with no sphere or lone triangle at
+    all in the second scene: the list / traverse / shade hand-over has nothing to fold with."""
+    from raytracing_amd import api
+    from raytracing_amd.scene_builder import SceneBuilder, load_golden_mesh
+
+    def with_spheres(from_rgb):
+        b = SceneBuilder(from_rgb)
+        b.add_model(np.zeros((0, 9)), b.material("Lambertian", (0.5, 0.5, 0.5)))
+        b.add_model(np.array([[0.0, -1.0, 0.2, 0.0, 1.0, 0.2, 0.0, 0.0, 1.8]]), b.material("Specular", (0.9, 0.9, 0.9)))
+        b.add_sphere((0.0, 0.0, 4.0), 1.5, material=b.material("Emitter", (1.0, 1.0, 1.0)))
+        b.add_sphere((0.0, 0.0, -1000.0), 1000.0, material=b.material("Lambertian", (0.4, 0.4, 0.4)))
+        return b
+
+    def meshes_only(from_rgb):
+        b = SceneBuilder(from_rgb)
+        room = load_golden_mesh("cubo")
+        b.add_model(room, b.material("Lambertian", (0.6, 0.6, 0.6)))                        # camera inside the cube
+        lamp = load_golden_mesh("cubo") * 0.15 + np.tile(np.array([0.0, 0.0, 2.0]), 3)
+        b.add_model(lamp, b.material("Emitter", (1.0, 0.9, 0.8)))
+        return b
+
+    cam_args = ((-2.5, 0.0, 1.0), 0.1, 100.0, (0.0, 0.2, 0.0), 128, 72)
+    for build in (with_spheres, meshes_only):
+        osc, ocam = O.Scene(*build(O.from_rgb).arrays()), O.camera(*cam_args)
+        gsc, gcam = api.Scene(ctx, *build(None).arrays()), api.camera_new(*cam_args)
+        for integrator, depth in ((O.INT_RANDOM_WALK, 6), (O.INT_NORMAL, 0)):
+            ref8, _, ref_lin, ref_st = osc.render(ocam, integrator, depth, 4, seed=8)
+            gpu8, gpu_xyz, st = gsc.render(gcam, api.render_params(integrator, depth, 4, seed=8))
+            assert ref8.any(), build.__name__
+            assert st["segments"] == ref_st.segments and st["paths"] == ref_st.paths
+            assert (gpu_xyz == ref_lin).all(axis=2).mean() >= 0.999, build.__name__
+            assert (gpu8 == ref8).mean() >= 0.995, build.__name__
+
+
 def test_small_batches_equal_large(ctx):
     """The batch size only changes scheduling, never the image."""
     from raytracing_amd import api
