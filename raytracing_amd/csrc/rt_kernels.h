@@ -118,18 +118,24 @@ void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const u
 //                   its idle lanes from its share of the list, and records the mesh hit per entry;
 //   shade_kernel    (dense, coherent)  for every path of level k: exact sphere / lone-triangle tests,
 //                   folded with the recorded mesh hit, shading, append of the continuing paths to level
-//                   k+1, and the listing of those whose new ray meets a mesh's box in `mesh_entries`.
+//                   k+1, those whose new ray meets a mesh's box at the front of their region, the rest at its back.
 // Level 0 has no queue: a path is recreated from its index (camera jitter or caller ray).
+// What traverse_kernel works through. Level 0: `entries` lists the positions of the primary rays that meet a mesh's
+// box (kShards regions of region_entries positions, region r fed by chunks c % kShards == r). Levels >= 1:
+// entries == nullptr, the work is the mesh class of the queue level itself (the front of each region).
 struct MeshList {
-  uint32_t* entries;   // kShards regions of region_entries path-queue positions, region r fed by chunks c % kShards == r
+  uint32_t* entries;
   uint32_t* counts;    // kShards fill counters, kCountStride apart, zeroed by the caller
 };
+// Fill counters of one queue level: per region, the paths whose ray meets a mesh's box are stored from the region's
+// front (`mesh`), the others from its back (`other`).
+struct LevelCounts { uint32_t* mesh; uint32_t* other; };
 // Rays of level 0 of a camera batch all start at the camera's focus; their entries hold only a direction.
 struct FixedOrigin { double x, y, z; bool fixed; };
 void launch_generate(const DevScene& sc, const BatchDesc& b, PathQueue q, uint32_t region_entries, MeshList mesh, hipStream_t s);
 // start: the paths are level 0 (max_in of them, recreated from their index); otherwise they are read from `in`
-void launch_shade(const DevScene& sc, const BatchDesc& b, bool start, PathQueue in, const uint32_t* in_counts, uint32_t max_in,
-                  PathQueue out, uint32_t* out_counts, uint32_t region_entries, MeshList mesh, TraceOutputs o, hipStream_t s);
+void launch_shade(const DevScene& sc, const BatchDesc& b, bool start, PathQueue in, LevelCounts in_counts, uint32_t max_in,
+                  PathQueue out, LevelCounts out_counts, uint32_t region_entries, TraceOutputs o, hipStream_t s);
 void launch_traverse(const DevScene& sc, PathQueue q, MeshList mesh, uint32_t max_in, uint32_t region_entries, FixedOrigin origin,
                      TraversalCounters* counters, hipStream_t s);
 // Forms the spectrum / XYZ of every queued emitter hit and writes the path's contribution.

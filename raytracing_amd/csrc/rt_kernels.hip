@@ -855,6 +855,61 @@ __device__ __forceinline__ bool queue_position(const uint32_t* s_prefix, const u
   return within < s_fill[lo];
 }
 
+// Two-kernel pipeline: a queue level keeps its paths in two classes per region. Class "mesh" (the new ray meets a
+// mesh's box, so traverse_kernel has work on it) fills a region from its front, class "other" from its back; each
+// has its own fill counter. traverse_kernel then reads its entries contiguously without a list, and shade_kernel's
+// waves are all-mesh or all-other, which keeps the lanes of a wave on the same shading branches.
+//   pseudo-region j < kShards : mesh class of region j, entry w at j * cap + w
+//   pseudo-region j >= kShards: other class of region j - kShards, entry w at (j - kShards) * cap + cap - 1 - w
+__device__ __forceinline__ uint32_t number_chunks2(const uint32_t* __restrict__ mesh_counts, const uint32_t* __restrict__ other_counts,
+                                                   uint32_t region_entries, uint32_t* s_prefix, uint32_t* s_fill) {
+  // one wave per class scans its kShards counters
+  if (threadIdx.x < 2 * kShards) {
+    const uint32_t cls = threadIdx.x / kShards, r = threadIdx.x % kShards;
+    uint32_t fill = (cls ? other_counts : mesh_counts)[r * kCountStride];
+    fill = fill < region_entries ? fill : region_entries;
+    uint32_t scan = (fill + kBlock - 1) / kBlock;
+    for (int off = 1; off < int(kShards); off <<= 1) {
+      const uint32_t up = __shfl_up(scan, off);
+      if (int(r) >= off) scan += up;
+    }
+    s_fill[threadIdx.x] = fill;
+    s_prefix[threadIdx.x + 1] = scan;     // per class for now
+    if (threadIdx.x == 0) s_prefix[0] = 0;
+  }
+  __syncthreads();
+  const uint32_t mesh_chunks = s_prefix[kShards];
+  __syncthreads();
+  if (threadIdx.x >= kShards && threadIdx.x < 2 * kShards) s_prefix[threadIdx.x + 1] += mesh_chunks;
+  __syncthreads();
+  return s_prefix[2 * kShards];
+}
+
+__device__ __forceinline__ bool queue_position2(const uint32_t* s_prefix, const uint32_t* s_fill, uint32_t region_entries,
+                                                uint32_t chunk, uint32_t& idx) {
+  uint32_t lo = 0, hi = 2 * kShards;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (s_prefix[mid] <= chunk) lo = mid; else hi = mid;
+  }
+  const uint32_t within = (chunk - s_prefix[lo]) * kBlock + threadIdx.x;
+  idx = lo < kShards ? lo * region_entries + within : (lo - kShards) * region_entries + (region_entries - 1u - within);
+  return within < s_fill[lo];
+}
+
+// Reserves a place for the lane's path in region chunk % kShards, in the mesh class (from the front) or the other
+// class (from the back). A region cannot overflow: both classes together receive at most the survivors of the
+// chunks that feed it. Must be reached by all lanes of the wave.
+__device__ __forceinline__ uint32_t reserve_by_class(uint32_t* mesh_counts, uint32_t* other_counts, uint32_t region_entries,
+                                                     uint32_t chunk, bool alive, bool meets_mesh) {
+  const uint32_t front = reserve_in_region(mesh_counts, region_entries, chunk, alive && meets_mesh);
+  const uint32_t back = reserve_in_region(other_counts, region_entries, chunk, alive && !meets_mesh);
+  if (!alive) return RT_MISS;
+  if (meets_mesh) return front;
+  const uint32_t region = chunk % kShards;
+  return region * region_entries + (region_entries - 1u - (back - region * region_entries));
+}
+
 // ------------------------------------------------------------------------------- the fused bounce kernel
 
 // One bounce for every path of a queue: closest hit, shading, append of the continuing paths.
@@ -938,21 +993,20 @@ generate_kernel(DevScene sc, BatchDesc b, PathQueue q, uint32_t region_entries, 
 // strict-'<' scan produces), hit point and normal for the winner only, shading, and the append of the
 // continuing paths to `out`. A new ray that meets a mesh's box is listed for the next traverse_kernel.
 template <bool START, bool EXT>
-__device__ __forceinline__ void shade_paths(const DevScene& sc, const BatchDesc& b, const PathQueue& in, const uint32_t* __restrict__ in_counts,
-                                            uint32_t region_entries, const PathQueue& out, uint32_t* __restrict__ out_counts,
-                                            const MeshList& mesh, const TraceOutputs& o) {
-  __shared__ uint32_t s_chunk_prefix[kShards + 1];
-  __shared__ uint32_t s_region_fill[kShards];
+__device__ __forceinline__ void shade_paths(const DevScene& sc, const BatchDesc& b, const PathQueue& in, LevelCounts in_counts,
+                                            uint32_t region_entries, const PathQueue& out, LevelCounts out_counts, const TraceOutputs& o) {
+  __shared__ uint32_t s_chunk_prefix[2 * kShards + 1];
+  __shared__ uint32_t s_region_fill[2 * kShards];
   const bool deep = b.max_depth > 16;
   const uint32_t n_start = b.rays ? b.n_rays : b.n_local_pixels * b.n_samples;
   const uint32_t n_chunks = START ? (n_start + kBlock - 1) / kBlock
-                                  : number_chunks(in_counts, region_entries, s_chunk_prefix, s_region_fill);
+                                  : number_chunks2(in_counts.mesh, in_counts.other, region_entries, s_chunk_prefix, s_region_fill);
 
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     uint32_t idx;
     bool active;
     if (START) { idx = chunk * kBlock + threadIdx.x; active = idx < n_start; }
-    else active = queue_position(s_chunk_prefix, s_region_fill, region_entries, chunk, idx);
+    else active = queue_position2(s_chunk_prefix, s_region_fill, region_entries, chunk, idx);
     PathState ps;
     ps.o = mk(0, 0, 0); ps.d = mk(1, 0, 0); ps.pixel = ps.sample = ps.slot = ps.remaining = 0;
     ps.chain.a = make_uint4(0, 0, 0, 0); ps.chain.b = make_uint4(0, 0, 0, 0);
@@ -984,15 +1038,12 @@ __device__ __forceinline__ void shade_paths(const DevScene& sc, const BatchDesc&
       sh = shade_hit<EXT>(sc, b, o, found, hit, first_hit, ps);
     }
     append_emit(sc, o, chunk, deep, sh.emits, sh.emit_info, ps.slot, ps.chain);
-    const uint32_t at = reserve_in_region(out_counts, region_entries, chunk, sh.alive);
-    bool meets_mesh = false;
+    const bool meets_mesh = sh.alive && meets_any_mesh(sc, sh.no, sh.nd);
+    const uint32_t at = reserve_by_class(out_counts.mesh, out_counts.other, region_entries, chunk, sh.alive, meets_mesh);
     if (sh.alive) {
       queue_store(out, at, sh.no, sh.nd, ps.pixel, ps.sample, ps.slot, ps.remaining - 1, ps.chain, deep);
       out.hit_obj()[at] = RT_MISS;
-      meets_mesh = meets_any_mesh(sc, sh.no, sh.nd);
     }
-    const uint32_t listed = reserve_in_region(mesh.counts, region_entries, chunk, meets_mesh);
-    if (meets_mesh) mesh.entries[listed] = at;
   }
 }
 
@@ -1000,16 +1051,16 @@ __device__ __forceinline__ void shade_paths(const DevScene& sc, const BatchDesc&
 // the allocator settles for by itself); the variant with the extension materials needs about 170 and is left alone.
 template <bool START>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
-shade_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_counts, uint32_t region_entries,
-             PathQueue out, uint32_t* __restrict__ out_counts, MeshList mesh, TraceOutputs o) {
-  shade_paths<START, false>(sc, b, in, in_counts, region_entries, out, out_counts, mesh, o);
+shade_kernel(DevScene sc, BatchDesc b, PathQueue in, LevelCounts in_counts, uint32_t region_entries, PathQueue out,
+             LevelCounts out_counts, TraceOutputs o) {
+  shade_paths<START, false>(sc, b, in, in_counts, region_entries, out, out_counts, o);
 }
 
 template <bool START>
 __global__ void __launch_bounds__(kBlock)
-shade_extended_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_counts, uint32_t region_entries,
-                      PathQueue out, uint32_t* __restrict__ out_counts, MeshList mesh, TraceOutputs o) {
-  shade_paths<START, true>(sc, b, in, in_counts, region_entries, out, out_counts, mesh, o);
+shade_extended_kernel(DevScene sc, BatchDesc b, PathQueue in, LevelCounts in_counts, uint32_t region_entries, PathQueue out,
+                      LevelCounts out_counts, TraceOutputs o) {
+  shade_paths<START, true>(sc, b, in, in_counts, region_entries, out, out_counts, o);
 }
 
 // Sparse half of a bounce: BVH traversal for the listed queue entries, by persistent waves. Each
@@ -1105,7 +1156,8 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
       const uint32_t g = next + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
       if (entry == RT_MISS && g < end) {
         const uint32_t region = find_region(s_prefix, g);
-        entry = mesh.entries[region * region_entries + (g - s_prefix[region])];
+        entry = region * region_entries + (g - s_prefix[region]);   // the mesh class of a level sits at the front of its regions
+        if (mesh.entries) entry = mesh.entries[entry];               // level 0: positions of the listed primary rays
         o = origin.fixed ? mk(origin.x, origin.y, origin.z) : mk(q.ox()[entry], q.oy()[entry], q.oz()[entry]);
         dn = normalize(mk(q.dx()[entry], q.dy()[entry], q.dz()[entry]));  // src/geometry/ray.rs:45
         m = 0; best_obj = RT_MISS;
@@ -1134,7 +1186,10 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
       if (n_walking + n_at_leaf == 0) break;
       const bool serviceable = cur == kDone && (refillable || (entry != RT_MISS && m + 1 < sc.n_meshes));
       if (uint32_t(__popcll(__ballot(serviceable))) >= kRefillLanes) break;
-      if (n_walking >= n_at_leaf) {
+#ifndef RT_LEAF_BIAS
+#define RT_LEAF_BIAS 8
+#endif
+      if (n_walking * 8u >= n_at_leaf * RT_LEAF_BIAS) {
         if (walking) {
           if (COUNT) count_slot(w_nodes);
           const uint4* np = node_words + (size_t(root) + cur) * 4;
@@ -1360,16 +1415,16 @@ void launch_generate(const DevScene& sc, const BatchDesc& b, PathQueue q, uint32
   hipLaunchKernelGGL(generate_kernel, dim3(grid_for(n)), kBlock, 0, s, sc, b, q, region_entries, mesh);
 }
 
-void launch_shade(const DevScene& sc, const BatchDesc& b, bool start, PathQueue in, const uint32_t* in_counts, uint32_t max_in,
-                  PathQueue out, uint32_t* out_counts, uint32_t region_entries, MeshList mesh, TraceOutputs o, hipStream_t s) {
+void launch_shade(const DevScene& sc, const BatchDesc& b, bool start, PathQueue in, LevelCounts in_counts, uint32_t max_in,
+                  PathQueue out, LevelCounts out_counts, uint32_t region_entries, TraceOutputs o, hipStream_t s) {
   if (max_in == 0) return;
-  const dim3 grid(grid_for(size_t(max_in) + (start ? 0 : size_t(kShards) * kBlock)));
+  const dim3 grid(grid_for(size_t(max_in) + (start ? 0 : 2 * size_t(kShards) * kBlock)));
   const int sel = (start ? 2 : 0) | (sc.extension_materials ? 1 : 0);
   switch (sel) {
-    case 0: hipLaunchKernelGGL((shade_kernel<false>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o); break;
-    case 1: hipLaunchKernelGGL((shade_extended_kernel<false>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o); break;
-    case 2: hipLaunchKernelGGL((shade_kernel<true>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o); break;
-    default: hipLaunchKernelGGL((shade_extended_kernel<true>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, mesh, o); break;
+    case 0: hipLaunchKernelGGL((shade_kernel<false>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, o); break;
+    case 1: hipLaunchKernelGGL((shade_extended_kernel<false>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, o); break;
+    case 2: hipLaunchKernelGGL((shade_kernel<true>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, o); break;
+    default: hipLaunchKernelGGL((shade_extended_kernel<true>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, o); break;
   }
 }
 

@@ -260,7 +260,7 @@ int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra
   // the emit queue's counters follow the last level, the per-level mesh lists' counters follow those
   const size_t emit_level = size_t(depth) + 2, mesh_level0 = emit_level + 1;
   const bool split = sc->dev.n_meshes > 0 && !sc->fused_only;
-  const size_t levels_used = split ? mesh_level0 + std::max<uint32_t>(depth, 1) : mesh_level0;
+  const size_t levels_used = split ? mesh_level0 + std::max<uint32_t>(depth, 1) + 1 : mesh_level0;
   HIP_TRY(hipMemsetAsync(counts, 0, levels_used * kCountLevelWords * sizeof(uint32_t), stream));
   const bool deep = depth > 16;
   if (depth >= 1 && ctx->emit_paths >= n_paths && (!deep || ctx->emit_deep) && !getenv("RTMI_INLINE_EMIT")) {
@@ -284,7 +284,9 @@ int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra
   } else {
     // level k >= 1 lives in queue[k & 1]; level 0 has no queue (queue[0] only carries the listed primary rays' directions and
     // the hit records, at the paths' own indices). Per level: traverse, then shade (which fills level k + 1).
-    auto mesh_list = [&](size_t k) { return MeshList{ctx->mesh_list.as<uint32_t>(), level_counts(mesh_level0 + k)}; };
+    // level k's fill counters: mesh class at level_counts(mesh_level0 + k), the rest at level_counts(k)
+    auto mesh_list = [&](size_t k) { return MeshList{k == 0 ? ctx->mesh_list.as<uint32_t>() : nullptr, level_counts(mesh_level0 + k)}; };
+    auto both = [&](size_t k) { return LevelCounts{level_counts(mesh_level0 + k), level_counts(k)}; };
     clock.begin();
     launch_generate(sc->dev, b, ctx->queue[0], region_entries, mesh_list(0), stream);
     clock.end();
@@ -296,15 +298,19 @@ int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra
       launch_traverse(sc->dev, ctx->queue[k & 1], mesh_list(k), uint32_t(n_paths), region_entries, origin, counters, stream);
       clock.end();
       clock.begin();
-      launch_shade(sc->dev, b, k == 0, ctx->queue[k & 1], level_counts(k), uint32_t(n_paths), ctx->queue[(k + 1) & 1], level_counts(k + 1),
-                   region_entries, mesh_list(k + 1 < levels ? k + 1 : k), o, stream);
+      launch_shade(sc->dev, b, k == 0, ctx->queue[k & 1], both(k), uint32_t(n_paths), ctx->queue[(k + 1) & 1], both(k + 1), region_entries, o,
+                   stream);
       clock.end();
       launches += 2;
     }
   }
   launch_emit(sc->dev, o, deep, uint32_t(n_paths), stream);
   if (depth > 1) launch_sum_counts(level_counts(1), depth - 1, &ds->bounce_segments, stream);
-  if (split) launch_sum_counts(level_counts(mesh_level0), std::max<uint32_t>(depth, 1), &ds->mesh_rays, stream);
+  if (split) {
+    launch_sum_counts(level_counts(mesh_level0), std::max<uint32_t>(depth, 1), &ds->mesh_rays, stream);
+    // bounce segments of the two-kernel pipeline: the mesh class of levels 1.. (the other class was summed above)
+    if (depth > 1) launch_sum_counts(level_counts(mesh_level0 + 1), depth - 1, &ds->bounce_segments, stream);
+  }
   HIP_TRY(hipGetLastError());
   return RTMI_OK;
 }
