@@ -193,6 +193,9 @@ def main():
                          "unit_of_work": unit_name, "bytes_per_unit": bytes_per_unit, "nodes_per_unit": nodes_per_unit,
                          "triangles_per_unit": tris_per_unit, "units_per_launch": units_per_launch,
                          "all_kernels_ms_per_step": kernel_ms / args.steps, "all_launches": launches,
+                         "note": "algorithmic bytes charge every BVH node and triangle fetch to memory; when the scene is "
+                                 "cache-resident they are cache hits, so frac can exceed 1 while `traffic` (HBM bytes per "
+                                 "launch from the committed PMC passes) stays far below it",
                          # the other term of the model: FP64-equivalent vector flops of the same launches
                          "valu": {"flops_per_unit": flops_per_unit, "achieved": valu_tflops, "peak": VALU_F64_PEAK_TFLOPS,
                                   "unit": "TFLOP/s", "frac": valu_tflops / VALU_F64_PEAK_TFLOPS}},
