@@ -21,9 +21,7 @@
 // binary64/binary32 arithmetic: a ray through an edge or a vertex, a grazing sphere hit and
 // every 60-bin product then decide and round exactly as the reference does. Only the BVH box
 // test, which is conservative by construction, asks for fused multiply-adds explicitly.
-#ifndef RT_ALLOW_FUSION
 #pragma clang fp contract(off)
-#endif
 
 namespace rtmi {
 
@@ -53,7 +51,6 @@ __device__ __forceinline__ V3 operator*(V3 a, double s) { return mk(a.x * s, a.y
 // the three, which yields the same correctly rounded results in 14 instructions fewer per division. Operands
 // far from 1 (where the expansion rescales its inputs) take the plain divisions.
 __device__ __forceinline__ V3 operator/(V3 a, double s) {
-#ifndef RT_EXP_PLAIN_DIV
   const double big = fmax(fmax(fabs(a.x), fabs(a.y)), fmax(fabs(a.z), fabs(s)));
   const double as = fabs(s);
   if (as > 0x1.0p-200 && big < 0x1.0p200) {
@@ -66,7 +63,6 @@ __device__ __forceinline__ V3 operator/(V3 a, double s) {
     return mk(__builtin_fma(__builtin_fma(-s, qx, a.x), r, qx), __builtin_fma(__builtin_fma(-s, qy, a.y), r, qy),
               __builtin_fma(__builtin_fma(-s, qz, a.z), r, qz));
   }
-#endif
   return mk(a.x / s, a.y / s, a.z / s);
 }
 __device__ __forceinline__ V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
@@ -74,11 +70,7 @@ __device__ __forceinline__ double dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
   return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-#ifdef RT_EXP_RCP_NORMALIZE
-__device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0 / sqrt(dot(a, a))); }
-#else
 __device__ __forceinline__ V3 normalize(V3 a) { return a / sqrt(dot(a, a)); }  // Ray::new, src/geometry/ray.rs:16
-#endif
 __device__ __forceinline__ V3 ld3(const double* p) { return mk(p[0], p[1], p[2]); }
 
 // row-major 3x4 affine map applied to a point / a vector / transposed linear part to a vector
@@ -222,46 +214,6 @@ __device__ __forceinline__ bool meets_box(const DevObject& ob, V3 o, const RayDi
   return slab32(ob.box_lo, ob.box_hi, br, INFINITY, tn);
 }
 
-#ifdef RT_TRI_FILTER
-// Cheap binary32 screen in front of the exact triangle test: returns false only when the exact
-// binary64 Moller-Trumbore is certain to reject. The same determinants are formed in binary32
-// (fused multiply-adds are fine here) and compared against bounds on their own error:
-//   rounding of U = p.tv, V = q.d      <= 21 * 2^-24 * s * D   (s = largest edge component, D = largest |tv| component)
-//   displacement of the ray by delta   <= 6 * s * delta
-//   rounding of det = p.e1             <= 15 * 2^-24 * s^2
-// The tolerances below (2^-18 s D + 8 s delta, 2^-18 s^2) carry a factor of three or more on top.
-__device__ __forceinline__ bool triangle_maybe_hit(const DevTriFilter& f, const BoxRay& r, float tmax) {
-  const float tx = r.ox - f.v0[0], ty = r.oy - f.v0[1], tz = r.oz - f.v0[2];
-  const float px = __builtin_fmaf(r.dy, f.e2[2], -(r.dz * f.e2[1]));
-  const float py = __builtin_fmaf(r.dz, f.e2[0], -(r.dx * f.e2[2]));
-  const float pz = __builtin_fmaf(r.dx, f.e2[1], -(r.dy * f.e2[0]));
-  const float qx = __builtin_fmaf(ty, f.e1[2], -(tz * f.e1[1]));
-  const float qy = __builtin_fmaf(tz, f.e1[0], -(tx * f.e1[2]));
-  const float qz = __builtin_fmaf(tx, f.e1[1], -(ty * f.e1[0]));
-  const float det = __builtin_fmaf(px, f.e1[0], __builtin_fmaf(py, f.e1[1], pz * f.e1[2]));
-  const float big_d = fmaxf(fmaxf(fabsf(tx), fabsf(ty)), fabsf(tz));
-  const float tol = f.scale * __builtin_fmaf(0x1.0p-18f, big_d, 8.0f * r.delta);
-  const float tol_det = 0x1.0p-18f * f.scale * f.scale;
-  const float ad = fabsf(det);
-  if (ad <= 4.0f * tol_det) return true;  // edge-on or tiny: let the exact test decide
-  const float u = copysignf(1.0f, det) * __builtin_fmaf(px, tx, __builtin_fmaf(py, ty, pz * tz));
-  const float v = copysignf(1.0f, det) * __builtin_fmaf(qx, r.dx, __builtin_fmaf(qy, r.dy, qz * r.dz));
-  const float t = copysignf(1.0f, det) * __builtin_fmaf(qx, f.e2[0], __builtin_fmaf(qy, f.e2[1], qz * f.e2[2]));
-  if (u < -tol || v < -tol || u + v > ad + 2.0f * tol + tol_det) return false;
-  const float tol_t = tol * f.scale;
-  if (t < -tol_t) return false;
-  if (t - tol_t > tmax * (ad + tol_det) * 1.00001f) return false;  // nearest rule only: tmax is +inf otherwise
-  return true;
-}
-#endif
-
-// Experiment knob: ask the register allocator for a given number of waves per SIMD.
-#ifdef RT_EXP_WAVES
-#define RT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(RT_EXP_WAVES, RT_EXP_WAVES)))
-#else
-#define RT_WAVES_ATTR
-#endif
-
 struct MeshHit { double t, t_raw; uint32_t index; uint32_t slot; };
 
 // Closest hit inside one mesh through its BVH. RULE = RT_HIT_FIRST_INDEX returns the hit
@@ -272,13 +224,10 @@ struct MeshHit { double t, t_raw; uint32_t index; uint32_t slot; };
 //
 // Two nested loops: lanes first walk inner nodes (cheap binary32 box tests) until each holds a
 // leaf or is done, then the wave does its leaves together, so the expensive triangle code runs
-// once per leaf a lane visits instead of once per node step of the slowest lane. Built with
-// -DRT_TRI_FILTER, triangles go through a binary32 screen first and only survivors take the exact
-// binary64 test; on the scenes measured so far the extra registers cost more than the screen saves,
-// so it is off by default.
+// once per leaf a lane visits instead of once per node step of the slowest lane.
 template <int RULE, bool COUNT>
 __device__ __forceinline__ bool mesh_closest(const uint4* __restrict__ nodes, const DevMeshTri* __restrict__ tris,
-                                             const DevTriFilter* __restrict__ filters, const DevObject& ob, V3 o, V3 d,
+                                             const DevObject& ob, V3 o, V3 d,
                                              uint32_t* stack, MeshHit& best, uint32_t& n_nodes, uint32_t& n_prims) {
   const BoxRay br = make_box_ray(o, d, ob);
   best.t = INFINITY; best.t_raw = 0.0; best.index = RT_MISS; best.slot = 0;
@@ -317,18 +266,9 @@ __device__ __forceinline__ bool mesh_closest(const uint4* __restrict__ nodes, co
     const uint32_t first = (cur & ~RT_LEAF_FLAG) >> 4, cnt = cur & 15u;
     for (uint32_t i = 0; i < cnt; ++i) {
       const DevMeshTri* tp = tris + first + i;
-#ifdef RT_TRI_FILTER
-      const DevTriFilter f = filters[first + i];
-      const uint32_t index = f.index;
-#else
       const uint32_t index = tp->index;
-#endif
       if (RULE == RT_HIT_FIRST_INDEX && index >= best.index) break;  // a leaf is sorted by index
       if (COUNT) ++n_prims;
-#ifdef RT_TRI_FILTER
-      const float tmax = RULE == RT_HIT_NEAREST ? __double2float_ru(best.t) * 1.000002f : INFINITY;
-      if (!triangle_maybe_hit(f, br, tmax)) continue;
-#endif
       const double2* q = reinterpret_cast<const double2*>(tp->v);
       const double2 a = q[0], b = q[1], c = q[2], e = q[3];
       const double last = tp->v[8];
@@ -394,8 +334,7 @@ __device__ __forceinline__ bool closest_hit(const DevScene& sc, const uint4* __r
       ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, t_raw, t);
     } else {
       MeshHit mh;
-      ok = mesh_closest<RULE, COUNT>(node_words + size_t(ob.root) * 4, sc.mesh_tris + ob.first, sc.mesh_filters + ob.first, ob,
-                                     o, dn, stack, mh, n_nodes, n_prims);
+      ok = mesh_closest<RULE, COUNT>(node_words + size_t(ob.root) * 4, sc.mesh_tris + ob.first, ob, o, dn, stack, mh, n_nodes, n_prims);
       t = mh.t; t_raw = mh.t_raw; prim = mh.index; slot = mh.slot;
     }
     if (ok && (!found || t < best_t)) {
@@ -468,10 +407,6 @@ __device__ __forceinline__ uint32_t chain_get(const Chain& c, uint32_t k) {
 // (src/spectrum/mod.rs:590-609). Exact binary32 products and sums, no contraction.
 __device__ __forceinline__ void emit_sample(const float* __restrict__ spectra, uint32_t emitted_row, const Chain& chain,
                                             uint32_t n_chain, float xyz[3], float* spectrum_out) {
-#ifdef RT_EXP_NO_EMIT
-  xyz[0] = xyz[1] = xyz[2] = float(emitted_row + n_chain + chain.a.x);
-  return;
-#endif
   float x = 0.0f, y = 0.0f, z = 0.0f;
   const float4* table = reinterpret_cast<const float4*>(spectra);
   for (int q = 0; q < RT_NBINS / 4; ++q) {
@@ -916,7 +851,7 @@ __device__ __forceinline__ uint32_t reserve_by_class(uint32_t* mesh_counts, uint
 // PRIMARY: the path starts here (camera ray from the Philox jitter, or a caller ray); otherwise
 // its state comes from `in`. Used for scenes without meshes, where every lane does the same work.
 template <bool PRIMARY, int RULE, bool COUNT, bool EXT>
-__global__ void __launch_bounds__(kBlock) RT_WAVES_ATTR
+__global__ void __launch_bounds__(kBlock)
 bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_counts, uint32_t region_entries,
               PathQueue out, uint32_t* __restrict__ out_counts, TraceOutputs o, TraversalCounters* counters) {
   extern __shared__ uint4 lds_dynamic[];
@@ -1082,7 +1017,7 @@ constexpr uint32_t kMinWaveShare = RT_MIN_WAVE_SHARE;   // entries; a smaller sh
 constexpr uint32_t kMaxRounds = RT_MAX_ROUNDS;
 
 template <int RULE, bool COUNT, bool STAGED>
-__global__ void __launch_bounds__(kBlock) RT_WAVES_ATTR
+__global__ void __launch_bounds__(kBlock)
 traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries, FixedOrigin origin, uint32_t resident_waves,
                 TraversalCounters* counters) {
   extern __shared__ uint4 lds_dynamic[];
@@ -1290,7 +1225,7 @@ struct HitOut { uint32_t obj, prim; double t; double p[3]; double n[3]; };
 static_assert(sizeof(HitOut) == 64, "hit record must be 64 bytes");
 
 template <int RULE, bool COUNT, bool STAGED>
-__global__ void __launch_bounds__(kBlock) RT_WAVES_ATTR
+__global__ void __launch_bounds__(kBlock)
 intersect_kernel(DevScene sc, const double* __restrict__ rays, size_t n, HitOut* __restrict__ hits, TraversalCounters* counters) {
   extern __shared__ uint4 lds_dynamic[];
   uint32_t* stack;

@@ -8,7 +8,6 @@
 //   top_tris  : lone triangles with their flat normal
 //   nodes     : one binary BVH per mesh, 64-byte nodes, all meshes concatenated
 //   mesh_tris : mesh triangles in BVH leaf order, f64 vertices + their file-order index
-//   mesh_filters : the same triangles as 48-byte binary32 digests for the conservative pre-test
 //   materials : type tag + indices into a table of 60-bin spectra
 #pragma once
 #include <stdint.h>
@@ -72,16 +71,6 @@ struct DevMeshTri {
 };
 static_assert(sizeof(DevMeshTri) == 80, "DevMeshTri must be 80 bytes");
 
-// Binary32 digest of a mesh triangle for the screen in front of the exact test: first vertex and
-// the two edges relative to the mesh centre, the largest absolute edge component, file-order index.
-struct DevTriFilter {
-  float v0[3], e1[3], e2[3];
-  float scale;
-  uint32_t index;
-  uint32_t pad;
-};
-static_assert(sizeof(DevTriFilter) == 48, "DevTriFilter must be 48 bytes");
-
 struct DevMaterial {
   uint32_t type;
   uint32_t present;
@@ -97,7 +86,6 @@ struct DevScene {
   const DevTopTri* top_tris;
   const BvhNode* nodes;
   const DevMeshTri* mesh_tris;
-  const DevTriFilter* mesh_filters;   // parallel to mesh_tris
   const DevMaterial* materials;
   const float* spectra;       // n_spectra x 60
   const uint32_t* mesh_objects;  // positions in `objects` of the models, ascending

@@ -90,7 +90,7 @@ struct rtmi_ctx {
 struct rtmi_scene {
   rtmi_ctx* ctx = nullptr;
   DevScene dev{};
-  DevBuf objects, spheres, top_tris, nodes, mesh_tris, mesh_filters, materials, spectra, mesh_objects;
+  DevBuf objects, spheres, top_tris, nodes, mesh_tris, materials, spectra, mesh_objects;
   rtmi_scene_info info{};
   // bookkeeping of the last render_accumulate, completed by rtmi_render_collect_stats
   rtmi_stats pending{};
@@ -463,7 +463,6 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   std::vector<DevTopTri> top_tris;
   std::vector<BvhNode> nodes;
   std::vector<DevMeshTri> mesh_tris;
-  std::vector<DevTriFilter> mesh_filters;
   std::vector<uint32_t> mesh_objects;
   uint32_t max_depth = 0;
   for (uint32_t i = 0; i < d->n_objects; ++i) {
@@ -520,21 +519,6 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
       mesh_objects.push_back(i);
       nodes.insert(nodes.end(), bb.nodes.begin(), bb.nodes.end());
       mesh_tris.insert(mesh_tris.end(), bb.tris.begin(), bb.tris.end());
-#ifdef RT_TRI_FILTER
-      for (const DevMeshTri& t : bb.tris) {
-        DevTriFilter f{};
-        float scale = 0.0f;
-        for (int k = 0; k < 3; ++k) {
-          f.v0[k] = float(t.v[k] - bb.center[k]);
-          f.e1[k] = float(t.v[3 + k] - t.v[k]);
-          f.e2[k] = float(t.v[6 + k] - t.v[k]);
-          scale = std::max(scale, std::max(std::fabs(f.e1[k]), std::fabs(f.e2[k])));
-        }
-        f.scale = scale * 1.000001f;
-        f.index = t.index;
-        mesh_filters.push_back(f);
-      }
-#endif
       max_depth = std::max(max_depth, bb.max_depth);
     } else {
       return fail(RTMI_UNSUPPORTED, "object %u has unknown kind %u", i, o.kind);
@@ -555,7 +539,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   s->ctx = ctx;
   int rc;
   if ((rc = upload(s->objects, objects)) || (rc = upload(s->spheres, spheres)) || (rc = upload(s->top_tris, top_tris)) ||
-      (rc = upload(s->nodes, nodes)) || (rc = upload(s->mesh_tris, mesh_tris)) || (rc = upload(s->mesh_filters, mesh_filters)) ||
+      (rc = upload(s->nodes, nodes)) || (rc = upload(s->mesh_tris, mesh_tris)) ||
       (rc = upload(s->materials, mats)) || (rc = upload(s->mesh_objects, mesh_objects)) ||
       (rc = upload(s->spectra, spectra))) {
     rtmi_scene_destroy(s.release());
@@ -563,7 +547,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   }
   s->dev.objects = s->objects.as<DevObject>(); s->dev.spheres = s->spheres.as<DevSphere>();
   s->dev.top_tris = s->top_tris.as<DevTopTri>(); s->dev.nodes = s->nodes.as<BvhNode>();
-  s->dev.mesh_tris = s->mesh_tris.as<DevMeshTri>(); s->dev.mesh_filters = s->mesh_filters.as<DevTriFilter>();
+  s->dev.mesh_tris = s->mesh_tris.as<DevMeshTri>();
   s->dev.materials = s->materials.as<DevMaterial>();
   s->dev.spectra = s->spectra.as<float>();
   s->dev.mesh_objects = s->mesh_objects.as<uint32_t>(); s->dev.n_meshes = uint32_t(mesh_objects.size());
@@ -574,7 +558,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   s->dev.lds_nodes = stage ? uint32_t(nodes.size()) : 0;
   s->info.n_nodes = uint32_t(nodes.size()); s->info.max_depth = max_depth;
   s->info.n_mesh_triangles = uint32_t(mesh_tris.size()); s->info.n_spectra = s->dev.n_spectra;
-  s->info.node_bytes = nodes.size() * sizeof(BvhNode); s->info.triangle_bytes = mesh_tris.size() * sizeof(DevMeshTri) + mesh_filters.size() * sizeof(DevTriFilter);
+  s->info.node_bytes = nodes.size() * sizeof(BvhNode); s->info.triangle_bytes = mesh_tris.size() * sizeof(DevMeshTri);
   *out = s.release();
   return RTMI_OK;
 }
@@ -582,7 +566,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
 extern "C" void rtmi_scene_destroy(rtmi_scene* s) {
   if (!s) return;
   if (s->ctx) { (void)hipSetDevice(s->ctx->device); (void)hipDeviceSynchronize(); }
-  for (DevBuf* b : {&s->objects, &s->spheres, &s->top_tris, &s->nodes, &s->mesh_tris, &s->mesh_filters, &s->materials, &s->spectra, &s->mesh_objects})
+  for (DevBuf* b : {&s->objects, &s->spheres, &s->top_tris, &s->nodes, &s->mesh_tris, &s->materials, &s->spectra, &s->mesh_objects})
     b->release();
   delete s;
 }
