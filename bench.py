@@ -33,7 +33,7 @@ VALU_F64_PEAK_TFLOPS = 78.6
 STATE_BYTES = 80
 
 WORKLOADS = {
-    # BASELINE.json configs[1]: Suzanne (968 triangles) + emitter + ground spheres, 1920x1080, 64 spp
+    # the headline configuration: Suzanne (968 triangles) + emitter + ground spheres, 1920x1080, 64 spp
     "suzanne_1080p_64spp": dict(recipe="scene2", width=1920, height=1080, spp=64, depth=10),
     "suzanne_specular_1080p_64spp": dict(recipe="scene2", width=1920, height=1080, spp=64, depth=10, specular_mesh=True),
     "scene1_400x225_100spp": dict(recipe="scene1", width=400, height=225, spp=100, depth=10),
