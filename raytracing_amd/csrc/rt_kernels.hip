@@ -151,9 +151,23 @@ __device__ __forceinline__ bool triangle_hit(V3 v0, V3 v1, V3 v2, V3 o, V3 dn, d
 
 // Sphere under an affine map (src/shapes/sphere.rs:50-103). t is measured along the
 // re-normalised local ray, as the reference reports it.
-__device__ __forceinline__ bool sphere_t(const DevSphere& s, V3 o, V3 d, double& t_out) {
-  const V3 lo = xf_pt(s.w2l, o);
-  const V3 ld = normalize(xf_vec(s.w2l, d));
+// The ray in a sphere's local frame: origin, and direction after the reference's re-normalisation
+// (src/shapes/sphere.rs:52, src/geometry/ray.rs:45). When the sphere's map is a pure translation (every
+// sphere the stock scenes have but one) the linear part multiplies the direction by exactly 1 and adds exact
+// zeros, so the local direction is the world direction and its normalisation is the `dn` the caller already
+// holds: a square root and three quotients saved per test. The one thing a product with the identity can
+// change is the sign of a zero, so directions with a zero component take the general path, which keeps the
+// results identical to the bit. (The origin always takes it: it costs little, and camera positions with a
+// zero coordinate are common.)
+__device__ __forceinline__ void sphere_local_ray(const DevSphere& s, V3 o, V3 d, V3 dn, V3& lo, V3& ld) {
+  lo = xf_pt(s.w2l, o);
+  if (s.translation_only && d.x != 0.0 && d.y != 0.0 && d.z != 0.0) ld = dn;
+  else ld = normalize(xf_vec(s.w2l, d));
+}
+
+__device__ __forceinline__ bool sphere_t(const DevSphere& s, V3 o, V3 d, V3 dn, double& t_out) {
+  V3 lo, ld;
+  sphere_local_ray(s, o, d, dn, lo, ld);
   const double h = dot(ld, lo);
   const double c = dot(lo, lo) - s.radius * s.radius;
   const double disc = h * h - c;
@@ -298,7 +312,8 @@ __device__ __forceinline__ void hit_geometry(const DevScene& sc, const DevObject
                                              uint32_t tri_slot, V3& p, V3& n) {
   if (ob.kind == RT_OBJ_SPHERE) {
     const DevSphere& s = sc.spheres[ob.first];
-    const V3 lo = xf_pt(s.w2l, o), ld = normalize(xf_vec(s.w2l, d));
+    V3 lo, ld;
+    sphere_local_ray(s, o, d, dn, lo, ld);
     const V3 pl = lo + ld * t;
     p = xf_pt(s.l2w, pl);                        // src/shapes/sphere.rs:98
     n = normalize(xf_vec_t(s.w2l, pl));          // src/shapes/sphere.rs:37-43
@@ -328,7 +343,7 @@ __device__ __forceinline__ bool closest_hit(const DevScene& sc, const uint4* __r
     bool ok;
     if (ob.kind != RT_OBJ_MODEL && !meets_box(ob, o, dir)) continue;
     if (ob.kind == RT_OBJ_SPHERE) {
-      ok = sphere_t(sc.spheres[ob.first], o, d, t);
+      ok = sphere_t(sc.spheres[ob.first], o, d, dn, t);
     } else if (ob.kind == RT_OBJ_TRIANGLE) {
       const DevTopTri& tr = sc.top_tris[ob.first];
       ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, t_raw, t);
@@ -359,7 +374,7 @@ __device__ __forceinline__ void simple_objects(const DevScene& sc, V3 o, V3 d, V
     bool ok;
     if (ob.kind == RT_OBJ_MODEL || !meets_box(ob, o, dir)) continue;
     if (ob.kind == RT_OBJ_SPHERE) {
-      ok = sphere_t(sc.spheres[ob.first], o, d, t);
+      ok = sphere_t(sc.spheres[ob.first], o, d, dn, t);
     } else {
       const DevTopTri& tr = sc.top_tris[ob.first];
       ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, t_raw, t);

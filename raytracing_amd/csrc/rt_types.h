@@ -45,7 +45,8 @@ struct DevSphere {
   double l2w[12];
   double w2l[12];
   double radius;
-  double pad;
+  uint32_t translation_only;   // the linear parts of both maps are exactly the identity
+  uint32_t pad;
 };
 
 struct DevTopTri {

@@ -476,6 +476,14 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
       std::memcpy(s.l2w, d->spheres[o.first].l2w, sizeof s.l2w);
       s.radius = d->spheres[o.first].radius;
       if (!affine_inverse(s.l2w, s.w2l)) return fail(RTMI_BAD_ARG, "object %u: sphere transform is singular", i);
+      s.translation_only = 1;
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          const double want = r == c ? 1.0 : 0.0;
+          // +0.0 exactly: a -0.0 entry would not add like a +0.0 one
+          if (s.l2w[r * 4 + c] != want || s.w2l[r * 4 + c] != want || std::signbit(s.l2w[r * 4 + c]) || std::signbit(s.w2l[r * 4 + c]))
+            s.translation_only = 0;
+        }
       dobj.first = uint32_t(spheres.size());
       spheres.push_back(s);
       // image of the radius-r sphere under the linear part: half extent along axis k = r * |row k|
