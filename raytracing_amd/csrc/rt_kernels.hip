@@ -60,8 +60,11 @@ __device__ __forceinline__ V3 operator/(V3 a, double s) {
     e = __builtin_fma(-s, r, 1.0);
     r = __builtin_fma(r, e, r);
     const double qx = a.x * r, qy = a.y * r, qz = a.z * r;
-    return mk(__builtin_fma(__builtin_fma(-s, qx, a.x), r, qx), __builtin_fma(__builtin_fma(-s, qy, a.y), r, qy),
-              __builtin_fma(__builtin_fma(-s, qz, a.z), r, qz));
+    // the sign is taken from the first estimate: for a zero numerator the correction step would yield +0 where the
+    // IEEE quotient of -0 is -0
+    return mk(__builtin_copysign(__builtin_fma(__builtin_fma(-s, qx, a.x), r, qx), qx),
+              __builtin_copysign(__builtin_fma(__builtin_fma(-s, qy, a.y), r, qy), qy),
+              __builtin_copysign(__builtin_fma(__builtin_fma(-s, qz, a.z), r, qz), qz));
   }
   return mk(a.x / s, a.y / s, a.z / s);
 }
@@ -131,26 +134,19 @@ __device__ __forceinline__ bool moller_trumbore(V3 v0, V3 v1, V3 v2, V3 o, V3 d,
   return true;
 }
 
-// The t the reference reports for a triangle hit at Moller-Trumbore distance t_raw (src/shapes/triangle.rs:30,92).
-__device__ __forceinline__ double reported_t(V3 v0, V3 v1, V3 v2, double t_raw) {
-  const V3 n = normalize(cross(v1 - v0, v2 - v0));
-  return t_raw / sqrt(dot(n, n));
-}
-
 // Triangle::intersect under the identity map every loader uses (src/shapes/triangle.rs:73-97).
 // `dn` is the ray direction after the reference's re-normalisation of the "local" ray
 // (src/geometry/ray.rs:45). Returns Moller-Trumbore's t (for the hit point) and the t the
-// reference reports, t / |n| with n the flat unit normal (src/shapes/triangle.rs:30,92).
-__device__ __forceinline__ bool triangle_hit(V3 v0, V3 v1, V3 v2, V3 o, V3 dn, double& t_raw, double& t_reported) {
+// reference reports, t / |n| with n the flat unit normal (src/shapes/triangle.rs:30,92); |n| is a
+// function of the vertices alone and comes precomputed (DevTriFrame::len).
+__device__ __forceinline__ bool triangle_hit(V3 v0, V3 v1, V3 v2, V3 o, V3 dn, double len, double& t_raw, double& t_reported) {
   double t;
   if (!moller_trumbore(v0, v1, v2, o, dn, t)) return false;
   t_raw = t;
-  t_reported = reported_t(v0, v1, v2, t);
+  t_reported = t / len;
   return true;
 }
 
-// Sphere under an affine map (src/shapes/sphere.rs:50-103). t is measured along the
-// re-normalised local ray, as the reference reports it.
 // The ray in a sphere's local frame: origin, and direction after the reference's re-normalisation
 // (src/shapes/sphere.rs:52, src/geometry/ray.rs:45). When the sphere's map is a pure translation (every
 // sphere the stock scenes have but one) the linear part multiplies the direction by exactly 1 and adds exact
@@ -241,7 +237,7 @@ struct MeshHit { double t, t_raw; uint32_t index; uint32_t slot; };
 // once per leaf a lane visits instead of once per node step of the slowest lane.
 template <int RULE, bool COUNT>
 __device__ __forceinline__ bool mesh_closest(const uint4* __restrict__ nodes, const DevMeshTri* __restrict__ tris,
-                                             const DevObject& ob, V3 o, V3 d,
+                                             const DevTriFrame* __restrict__ frames, const DevObject& ob, V3 o, V3 d,
                                              uint32_t* stack, MeshHit& best, uint32_t& n_nodes, uint32_t& n_prims) {
   const BoxRay br = make_box_ray(o, d, ob);
   best.t = INFINITY; best.t_raw = 0.0; best.index = RT_MISS; best.slot = 0;
@@ -287,7 +283,7 @@ __device__ __forceinline__ bool mesh_closest(const uint4* __restrict__ nodes, co
       const double2 a = q[0], b = q[1], c = q[2], e = q[3];
       const double last = tp->v[8];
       double t_raw, t;
-      if (triangle_hit(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), mk(e.x, e.y, last), o, d, t_raw, t)) {
+      if (triangle_hit(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), mk(e.x, e.y, last), o, d, frames[first + i].len, t_raw, t)) {
         if (RULE == RT_HIT_FIRST_INDEX) {
           best.t = t; best.t_raw = t_raw; best.index = index; best.slot = first + i;
           break;
@@ -318,10 +314,9 @@ __device__ __forceinline__ void hit_geometry(const DevScene& sc, const DevObject
     p = xf_pt(s.l2w, pl);                        // src/shapes/sphere.rs:98
     n = normalize(xf_vec_t(s.w2l, pl));          // src/shapes/sphere.rs:37-43
   } else {
-    const double* v = ob.kind == RT_OBJ_TRIANGLE ? sc.top_tris[ob.first].v : sc.mesh_tris[ob.first + tri_slot].v;
-    const V3 v0 = ld3(v), v1 = ld3(v + 3), v2 = ld3(v + 6);
+    const DevTriFrame& f = ob.kind == RT_OBJ_TRIANGLE ? sc.top_tris[ob.first].frame : sc.mesh_frames[ob.first + tri_slot];
     p = o + dn * t_raw;                                          // src/shapes/triangle.rs:78-81
-    n = normalize(normalize(cross(v1 - v0, v2 - v0)));          // src/shapes/triangle.rs:30, then :91
+    n = ld3(f.n);                                                // src/shapes/triangle.rs:30, then :91
   }
 }
 
@@ -346,10 +341,11 @@ __device__ __forceinline__ bool closest_hit(const DevScene& sc, const uint4* __r
       ok = sphere_t(sc.spheres[ob.first], o, d, dn, t);
     } else if (ob.kind == RT_OBJ_TRIANGLE) {
       const DevTopTri& tr = sc.top_tris[ob.first];
-      ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, t_raw, t);
+      ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, tr.frame.len, t_raw, t);
     } else {
       MeshHit mh;
-      ok = mesh_closest<RULE, COUNT>(node_words + size_t(ob.root) * 4, sc.mesh_tris + ob.first, ob, o, dn, stack, mh, n_nodes, n_prims);
+      ok = mesh_closest<RULE, COUNT>(node_words + size_t(ob.root) * 4, sc.mesh_tris + ob.first, sc.mesh_frames + ob.first, ob, o, dn, stack, mh,
+                                     n_nodes, n_prims);
       t = mh.t; t_raw = mh.t_raw; prim = mh.index; slot = mh.slot;
     }
     if (ok && (!found || t < best_t)) {
@@ -377,7 +373,7 @@ __device__ __forceinline__ void simple_objects(const DevScene& sc, V3 o, V3 d, V
       ok = sphere_t(sc.spheres[ob.first], o, d, dn, t);
     } else {
       const DevTopTri& tr = sc.top_tris[ob.first];
-      ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, t_raw, t);
+      ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, tr.frame.len, t_raw, t);
     }
     if (ok && (best.obj == RT_MISS || t < best.t)) { best.t = t; best.t_raw = t_raw; best.obj = i; }
   }
@@ -1086,8 +1082,7 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
     if (COUNT) { count_slot(w_service); if (cur == kDone) ++n_service; }
     if (cur == kDone && entry != RT_MISS) {
       if (RULE == RT_HIT_FIRST_INDEX && mh.index != RT_MISS) {
-        const double* v = sc.mesh_tris[first_tri + mh.slot].v;
-        mh.t = reported_t(ld3(v), ld3(v + 3), ld3(v + 6), mh.t_raw);
+        mh.t = mh.t_raw / sc.mesh_frames[first_tri + mh.slot].len;
       }
       // meshes are visited in scene order, so strict '<' keeps the earlier object on a tie
       if (mh.index != RT_MISS && (best_obj == RT_MISS || mh.t < best_t)) {
@@ -1187,7 +1182,7 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
               mh.t_raw = t_raw; mh.index = index; mh.slot = slot;
               leaf_done = true;
             }
-          } else if (triangle_hit(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), mk(e.x, e.y, last), o, dn, t_raw, t)) {
+          } else if (triangle_hit(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), mk(e.x, e.y, last), o, dn, sc.mesh_frames[first_tri + slot].len, t_raw, t)) {
             if (t < mh.t || (t == mh.t && index < mh.index)) {
               mh.t = t; mh.t_raw = t_raw; mh.index = index; mh.slot = slot;
             }

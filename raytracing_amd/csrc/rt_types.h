@@ -8,6 +8,7 @@
 //   top_tris  : lone triangles with their flat normal
 //   nodes     : one binary BVH per mesh, 64-byte nodes, all meshes concatenated
 //   mesh_tris : mesh triangles in BVH leaf order, f64 vertices + their file-order index
+//   mesh_frames : per mesh triangle, the normal and the divisor of the reported t (functions of the vertices alone)
 //   materials : type tag + indices into a table of 60-bin spectra
 #pragma once
 #include <stdint.h>
@@ -49,9 +50,17 @@ struct DevSphere {
   uint32_t pad;
 };
 
+// What the reference derives from a triangle's vertices alone, formed once on the host with the same IEEE
+// operations (src/shapes/triangle.rs:30,83,91-92): n1 = normalize((p2-p1) x (p3-p1)), mapped through the identity
+// local->world matrix, is the normal of a hit before normalisation; a hit reports t / |n1| and normalize(n1).
+struct DevTriFrame {
+  double n[3];         // normalize(n1)
+  double len;          // sqrt(n1 . n1)
+};
+
 struct DevTopTri {
   double v[9];
-  double n[3];         // normalize((p2-p1) x (p3-p1)), src/shapes/triangle.rs:30
+  DevTriFrame frame;
 };
 
 // Child reference: RT_LEAF_FLAG | first << 4 | count for a leaf (first is relative to the
@@ -87,6 +96,7 @@ struct DevScene {
   const DevTopTri* top_tris;
   const BvhNode* nodes;
   const DevMeshTri* mesh_tris;
+  const DevTriFrame* mesh_frames;   // parallel to mesh_tris
   const DevMaterial* materials;
   const float* spectra;       // n_spectra x 60
   const uint32_t* mesh_objects;  // positions in `objects` of the models, ascending

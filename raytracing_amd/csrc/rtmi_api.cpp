@@ -90,7 +90,7 @@ struct rtmi_ctx {
 struct rtmi_scene {
   rtmi_ctx* ctx = nullptr;
   DevScene dev{};
-  DevBuf objects, spheres, top_tris, nodes, mesh_tris, materials, spectra, mesh_objects;
+  DevBuf objects, spheres, top_tris, nodes, mesh_tris, mesh_frames, materials, spectra, mesh_objects;
   rtmi_scene_info info{};
   // bookkeeping of the last render_accumulate, completed by rtmi_render_collect_stats
   rtmi_stats pending{};
@@ -192,6 +192,23 @@ void set_object_box(DevObject& ob, const double* lo, const double* hi) {
     if (double(h) < dh) h = std::nextafterf(h, FLT_MAX);
     ob.box_lo[k] = l; ob.box_hi[k] = h;
   }
+}
+
+// normalize((v1-v0) x (v2-v0)), its length and its normalisation, in the reference's operation order (this file is
+// compiled without contraction, so every product and sum rounds separately, as on the device)
+DevTriFrame tri_frame(const double* v) {
+  const double e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
+  const double c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+  const double cl = std::sqrt((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]);
+  const double n0[3] = {c[0] / cl, c[1] / cl, c[2] / cl};
+  // the reference then maps the normal through the triangle's (identity) local->world matrix
+  // (src/shapes/triangle.rs:83); the products with 1 and 0 are exact but turn a -0 component into +0
+  const double n1[3] = {(1.0 * n0[0] + 0.0 * n0[1]) + 0.0 * n0[2], (0.0 * n0[0] + 1.0 * n0[1]) + 0.0 * n0[2],
+                        (0.0 * n0[0] + 0.0 * n0[1]) + 1.0 * n0[2]};
+  DevTriFrame f;
+  f.len = std::sqrt((n1[0] * n1[0] + n1[1] * n1[1]) + n1[2] * n1[2]);
+  for (int k = 0; k < 3; ++k) f.n[k] = n1[k] / f.len;
+  return f;
 }
 
 template <class T>
@@ -463,6 +480,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   std::vector<DevTopTri> top_tris;
   std::vector<BvhNode> nodes;
   std::vector<DevMeshTri> mesh_tris;
+  std::vector<DevTriFrame> mesh_frames;
   std::vector<uint32_t> mesh_objects;
   uint32_t max_depth = 0;
   for (uint32_t i = 0; i < d->n_objects; ++i) {
@@ -499,10 +517,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
       DevTopTri t{};
       std::memcpy(t.v, d->triangles[o.first].v, sizeof t.v);
       const double* v = t.v;
-      const double e1[3] = {v[3] - v[0], v[4] - v[1], v[5] - v[2]}, e2[3] = {v[6] - v[0], v[7] - v[1], v[8] - v[2]};
-      const double c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-      const double len = std::sqrt((c[0] * c[0] + c[1] * c[1]) + c[2] * c[2]);
-      for (int k = 0; k < 3; ++k) t.n[k] = c[k] / len;
+      t.frame = tri_frame(v);
       dobj.first = uint32_t(top_tris.size());
       top_tris.push_back(t);
       double lo[3], hi[3];
@@ -527,6 +542,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
       mesh_objects.push_back(i);
       nodes.insert(nodes.end(), bb.nodes.begin(), bb.nodes.end());
       mesh_tris.insert(mesh_tris.end(), bb.tris.begin(), bb.tris.end());
+      for (const DevMeshTri& t : bb.tris) mesh_frames.push_back(tri_frame(t.v));
       max_depth = std::max(max_depth, bb.max_depth);
     } else {
       return fail(RTMI_UNSUPPORTED, "object %u has unknown kind %u", i, o.kind);
@@ -547,7 +563,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   s->ctx = ctx;
   int rc;
   if ((rc = upload(s->objects, objects)) || (rc = upload(s->spheres, spheres)) || (rc = upload(s->top_tris, top_tris)) ||
-      (rc = upload(s->nodes, nodes)) || (rc = upload(s->mesh_tris, mesh_tris)) ||
+      (rc = upload(s->nodes, nodes)) || (rc = upload(s->mesh_tris, mesh_tris)) || (rc = upload(s->mesh_frames, mesh_frames)) ||
       (rc = upload(s->materials, mats)) || (rc = upload(s->mesh_objects, mesh_objects)) ||
       (rc = upload(s->spectra, spectra))) {
     rtmi_scene_destroy(s.release());
@@ -555,7 +571,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   }
   s->dev.objects = s->objects.as<DevObject>(); s->dev.spheres = s->spheres.as<DevSphere>();
   s->dev.top_tris = s->top_tris.as<DevTopTri>(); s->dev.nodes = s->nodes.as<BvhNode>();
-  s->dev.mesh_tris = s->mesh_tris.as<DevMeshTri>();
+  s->dev.mesh_tris = s->mesh_tris.as<DevMeshTri>(); s->dev.mesh_frames = s->mesh_frames.as<DevTriFrame>();
   s->dev.materials = s->materials.as<DevMaterial>();
   s->dev.spectra = s->spectra.as<float>();
   s->dev.mesh_objects = s->mesh_objects.as<uint32_t>(); s->dev.n_meshes = uint32_t(mesh_objects.size());
@@ -566,7 +582,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   s->dev.lds_nodes = stage ? uint32_t(nodes.size()) : 0;
   s->info.n_nodes = uint32_t(nodes.size()); s->info.max_depth = max_depth;
   s->info.n_mesh_triangles = uint32_t(mesh_tris.size()); s->info.n_spectra = s->dev.n_spectra;
-  s->info.node_bytes = nodes.size() * sizeof(BvhNode); s->info.triangle_bytes = mesh_tris.size() * sizeof(DevMeshTri);
+  s->info.node_bytes = nodes.size() * sizeof(BvhNode); s->info.triangle_bytes = mesh_tris.size() * (sizeof(DevMeshTri) + sizeof(DevTriFrame));
   *out = s.release();
   return RTMI_OK;
 }
@@ -574,7 +590,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
 extern "C" void rtmi_scene_destroy(rtmi_scene* s) {
   if (!s) return;
   if (s->ctx) { (void)hipSetDevice(s->ctx->device); (void)hipDeviceSynchronize(); }
-  for (DevBuf* b : {&s->objects, &s->spheres, &s->top_tris, &s->nodes, &s->mesh_tris, &s->materials, &s->spectra, &s->mesh_objects})
+  for (DevBuf* b : {&s->objects, &s->spheres, &s->top_tris, &s->nodes, &s->mesh_tris, &s->mesh_frames, &s->materials, &s->spectra, &s->mesh_objects})
     b->release();
   delete s;
 }
