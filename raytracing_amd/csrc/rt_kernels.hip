@@ -1015,7 +1015,7 @@ shade_extended_kernel(DevScene sc, BatchDesc b, PathQueue in, LevelCounts in_cou
 // as many steps as others. Lanes are serviced (retired, moved to the next mesh, refilled) in groups
 // of at least kRefillLanes to keep that bookkeeping off the traversal's critical path.
 #ifndef RT_REFILL_LANES
-#define RT_REFILL_LANES 48
+#define RT_REFILL_LANES 40
 #endif
 #ifndef RT_MIN_WAVE_SHARE
 #define RT_MIN_WAVE_SHARE 512
