@@ -74,7 +74,11 @@ class Context:
             L.lib().rtmi_ctx_destroy(self.handle)
             self.handle = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: module globals may already be gone; the process frees the GPU
+            pass
 
     def tonemap(self, xyz_sum_ptr, spp, width, height, rgb8_ptr, stream=0):
         L.check(L.lib().rtmi_tonemap(self.handle, C.c_void_p(xyz_sum_ptr), int(spp), int(width), int(height),
@@ -102,7 +106,11 @@ class Scene:
             L.lib().rtmi_scene_destroy(self.handle)
             self.handle = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: module globals may already be gone
+            pass
 
     def info(self):
         i = L.SceneInfo()
