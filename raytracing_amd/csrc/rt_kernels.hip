@@ -1074,13 +1074,14 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
   double best_t = 0.0, best_raw = 0.0;     // best over the meshes done so far
   uint32_t best_obj = RT_MISS, best_prim = 0, best_slot = 0;
   uint32_t cur = kDone;
-  uint32_t leaf_i = 0;                     // next triangle of the leaf the lane is at
+  constexpr uint32_t kNoLeaf = 0u;         // a leaf reference always has its flag bit set
+  uint32_t lf = kNoLeaf;                   // the leaf whose triangles the lane is testing, counting itself down
   int sp = 0;
 
   for (;;) {
     // ---- service: every lane whose traversal has ended
-    if (COUNT) { count_slot(w_service); if (cur == kDone) ++n_service; }
-    if (cur == kDone && entry != RT_MISS) {
+    if (COUNT) { count_slot(w_service); if (cur == kDone && lf == kNoLeaf) ++n_service; }
+    if (cur == kDone && lf == kNoLeaf && entry != RT_MISS) {
       if (RULE == RT_HIT_FIRST_INDEX && mh.index != RT_MISS) {
         mh.t = mh.t_raw / sc.mesh_frames[first_tri + mh.slot].len;
       }
@@ -1110,7 +1111,7 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
       const uint32_t taken = uint32_t(__popcll(idle));
       next = end - next < taken ? end : next + taken;
     }
-    if (cur == kDone && entry != RT_MISS) {   // enter mesh m
+    if (cur == kDone && lf == kNoLeaf && entry != RT_MISS) {   // enter mesh m
       const DevObject ob = sc.objects[sc.mesh_objects[m]];
       br = make_box_ray(o, dn, ob);
       root = ob.root; first_tri = ob.first;
@@ -1120,21 +1121,25 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
     if (__ballot(entry != RT_MISS) == 0) break;
     const bool refillable = next < end;
 
-    // ---- traverse until enough lanes can be given new work. Every lane with a ray is in one of two states: at an
-    // inner node (needs a box-test step) or at a leaf (needs a triangle test). Each wave-level iteration runs the step
-    // that more lanes are waiting for; the others keep their state. Letting every lane finish its run of nodes before
-    // any leaf was touched left the node step at 27 % lane occupancy and the triangle step at 40 %.
+    // ---- traverse until enough lanes can be given new work. A lane with a ray may need a box-test step (cur is an
+    // inner node), a triangle test (it holds a leaf in `lf`), or both: a lane that reaches a leaf parks it in `lf` and
+    // walks on, so it only stalls when it reaches a second leaf before the first is done. Each wave-level iteration
+    // runs the step that more lanes are waiting for. (Letting every lane finish its run of nodes before any leaf was
+    // touched left the node step at 27 % lane occupancy and the triangle step at 40 %.) `lf` counts itself down: after
+    // each tested triangle its first-triangle field goes up and its count field down.
     for (;;) {
+      if ((cur & RT_LEAF_FLAG) && cur != kDone && lf == kNoLeaf) {   // park the leaf, keep walking
+        lf = cur;
+        cur = sp ? stack[(--sp) * kBlock] : kDone;
+      }
       const bool walking = !(cur & RT_LEAF_FLAG);
-      const bool at_leaf = !walking && cur != kDone;
-      const uint32_t n_walking = uint32_t(__popcll(__ballot(walking))), n_at_leaf = uint32_t(__popcll(__ballot(at_leaf)));
-      if (n_walking + n_at_leaf == 0) break;
-      const bool serviceable = cur == kDone && (refillable || (entry != RT_MISS && m + 1 < sc.n_meshes));
+      const bool has_leaf = lf != kNoLeaf;
+      const uint32_t n_walking = uint32_t(__popcll(__ballot(walking))), n_leaf = uint32_t(__popcll(__ballot(has_leaf)));
+      if (n_walking + n_leaf == 0) break;
+      const bool finished = cur == kDone && !has_leaf;
+      const bool serviceable = finished && (refillable || (entry != RT_MISS && m + 1 < sc.n_meshes));
       if (uint32_t(__popcll(__ballot(serviceable))) >= kRefillLanes) break;
-#ifndef RT_LEAF_BIAS
-#define RT_LEAF_BIAS 8
-#endif
-      if (n_walking * 8u >= n_at_leaf * RT_LEAF_BIAS) {
+      if (n_walking >= n_leaf) {
         if (walking) {
           if (COUNT) count_slot(w_nodes);
           const uint4* np = node_words + (size_t(root) + cur) * 4;
@@ -1161,12 +1166,10 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
           } else {
             cur = sp ? stack[(--sp) * kBlock] : kDone;
           }
-          leaf_i = 0;
         }
-      } else if (at_leaf) {
+      } else if (has_leaf) {
         if (COUNT) count_slot(w_prims);
-        const uint32_t first = (cur & ~RT_LEAF_FLAG) >> 4, cnt = cur & 15u;
-        const uint32_t slot = first + leaf_i;
+        const uint32_t slot = (lf & ~RT_LEAF_FLAG) >> 4;
         const DevMeshTri* tp = sc.mesh_tris + first_tri + slot;
         const uint32_t index = tp->index;
         bool leaf_done = RULE == RT_HIT_FIRST_INDEX && index >= mh.index;   // a leaf is sorted by index
@@ -1187,12 +1190,10 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
               mh.t = t; mh.t_raw = t_raw; mh.index = index; mh.slot = slot;
             }
           }
-          leaf_done = leaf_done || ++leaf_i == cnt;
+          lf += 15u;                                   // first + 1 (bit 4 up), count - 1
+          leaf_done = leaf_done || (lf & 15u) == 0u;
         }
-        if (leaf_done) {
-          cur = sp ? stack[(--sp) * kBlock] : kDone;
-          leaf_i = 0;
-        }
+        if (leaf_done) lf = kNoLeaf;
       }
     }
   }
