@@ -995,11 +995,19 @@ __device__ __forceinline__ void shade_paths(const DevScene& sc, const BatchDesc&
 
 // The reference's three material types fit in 128 registers, i.e. four waves per SIMD (measured +4 % over the three
 // the allocator settles for by itself); the variant with the extension materials needs about 170 and is left alone.
-template <bool START>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
 shade_kernel(DevScene sc, BatchDesc b, PathQueue in, LevelCounts in_counts, uint32_t region_entries, PathQueue out,
              LevelCounts out_counts, TraceOutputs o) {
-  shade_paths<START, false>(sc, b, in, in_counts, region_entries, out, out_counts, o);
+  shade_paths<false, false>(sc, b, in, in_counts, region_entries, out, out_counts, o);
+}
+
+#ifndef RT_START_WAVES
+#define RT_START_WAVES 4
+#endif
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_START_WAVES, RT_START_WAVES)))
+shade_start_kernel(DevScene sc, BatchDesc b, PathQueue in, LevelCounts in_counts, uint32_t region_entries, PathQueue out,
+                   LevelCounts out_counts, TraceOutputs o) {
+  shade_paths<true, false>(sc, b, in, in_counts, region_entries, out, out_counts, o);
 }
 
 template <bool START>
@@ -1367,9 +1375,9 @@ void launch_shade(const DevScene& sc, const BatchDesc& b, bool start, PathQueue 
   const dim3 grid(grid_for(size_t(max_in) + (start ? 0 : 2 * size_t(kShards) * kBlock)));
   const int sel = (start ? 2 : 0) | (sc.extension_materials ? 1 : 0);
   switch (sel) {
-    case 0: hipLaunchKernelGGL((shade_kernel<false>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, o); break;
+    case 0: hipLaunchKernelGGL(shade_kernel, grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, o); break;
     case 1: hipLaunchKernelGGL((shade_extended_kernel<false>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, o); break;
-    case 2: hipLaunchKernelGGL((shade_kernel<true>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, o); break;
+    case 2: hipLaunchKernelGGL(shade_start_kernel, grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, o); break;
     default: hipLaunchKernelGGL((shade_extended_kernel<true>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, o); break;
   }
 }
