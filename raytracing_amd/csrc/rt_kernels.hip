@@ -1,11 +1,12 @@
 // rt_kernels.hip -- gfx950 kernels of the path-tracing hot path.
 //
-// Wavefront path tracing: one kernel launch per bounce. A launch takes every path of the
-// current queue through closest-hit + material shading and appends the paths that continue to
-// the next queue with one wave-wide ballot and one atomic per wave (no megakernel, no
-// recursion). Geometry arithmetic is binary64 like the reference's; spectra are binary32.
-// A path does not carry a 60-bin throughput: it records, per hit, which spectrum-table row
-// it picked up (one byte), and the 60-bin product is formed once, when the path reaches an
+// Wavefront path tracing, no megakernel and no recursion. Scenes without meshes run one fused kernel per
+// bounce (bounce_kernel: closest hit, shading, append of the paths that continue). Scenes with meshes run two
+// per bounce: shade_kernel (dense: exact sphere / triangle tests, shading, append) and traverse_kernel
+// (persistent waves that walk the BVHs for the mesh-bound rays only and refill their idle lanes). Paths are
+// appended with one wave-wide ballot and one atomic per wave. Geometry arithmetic is binary64 like the
+// reference's; spectra are binary32. A path does not carry a 60-bin throughput: it records, per hit, which
+// spectrum-table row it picked up (one byte), and the 60-bin product is formed once, when the path reaches an
 // emitter, in the reference's multiplication order.
 //
 // Citations are file:line in the reference repository.
