@@ -20,8 +20,9 @@
 
 // Products and sums stay separately rounded in this file, as in the reference's (unfused)
 // binary64/binary32 arithmetic: a ray through an edge or a vertex, a grazing sphere hit and
-// every 60-bin product then decide and round exactly as the reference does. Only the BVH box
-// test, which is conservative by construction, asks for fused multiply-adds explicitly.
+// every 60-bin product then decide and round exactly as the reference does. Fused multiply-adds
+// are written out only in operator/(V3, double), whose refinement steps are those of the correctly
+// rounded division itself.
 #pragma clang fp contract(off)
 
 namespace rtmi {
