@@ -935,6 +935,61 @@ generate_kernel(DevScene sc, BatchDesc b, PathQueue q, uint32_t region_entries, 
   }
 }
 
+// Can any ray through pixel (x, y) -- whatever its jitter -- meet the bounding sphere of a mesh? The rays of a pixel
+// lie in a cone about the ray through the pixel's centre whose half-angle is at most (half the pixel's diagonal on
+// the screen) / (distance from the focus to the pixel); a mesh is out of reach when its centre direction is further
+// from the axis than that plus the sphere's angular radius. Angles are compared through sines and cosines with a
+// 50 % allowance on the cone and 1e-6 on the comparison, so the answer errs towards "yes".
+__device__ __forceinline__ bool pixel_may_see_mesh(const DevScene& sc, const DevCamera& cam, uint32_t x, uint32_t y) {
+  const V3 p1 = ld3(cam.p1), f = ld3(cam.focus);
+  const V3 ex = (ld3(cam.p2) - p1) * (1.0 / double(cam.width)), ey = (ld3(cam.p3) - p1) * (1.0 / double(cam.height));
+  const V3 axis = ((p1 + ex * double(x)) + ey * double(y)) - f;
+  const double axis_len = sqrt(dot(axis, axis));
+  const double half_diag = 0.5 * (sqrt(dot(ex, ex)) + sqrt(dot(ey, ey)));
+  const double sin_a = 1.5 * half_diag / axis_len;           // >= sin of the cone's half-angle
+  if (!(sin_a < 0.1)) return true;                            // enormous pixels: no culling
+  const double cos_a = 1.0 - sin_a * sin_a;                   // <= cos of it
+  for (uint32_t k = 0; k < sc.n_meshes; ++k) {
+    const DevObject& ob = sc.objects[sc.mesh_objects[k]];
+    const V3 v = ld3(ob.center) - f;
+    const double dist = sqrt(dot(v, v));
+    const double sin_b = ob.radius * 1.000001 / dist;         // sine of the sphere's angular radius
+    if (!(sin_b < 0.999)) return true;                        // the focus is inside or next to the sphere
+    const double cos_b = sqrt(1.0 - sin_b * sin_b);
+    const double cos_t = dot(axis, v) / (axis_len * dist);    // cosine of the angle between axis and centre
+    if (cos_t >= (cos_a * cos_b - sin_a * sin_b) - 1e-6) return true;   // angle <= a + b
+  }
+  return false;
+}
+
+// The same for the camera rays of a batch, one lane per pixel looping over the pixel's samples: pixels that cannot see
+// a mesh (most of them, as a rule) only clear their hit records and never generate a ray here.
+__global__ void __launch_bounds__(kBlock)
+generate_camera_kernel(DevScene sc, BatchDesc b, PathQueue q, uint32_t region_entries, MeshList mesh) {
+  const uint32_t n_chunks = (b.n_local_pixels + kBlock - 1) / kBlock;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t lp = chunk * kBlock + threadIdx.x;
+    uint32_t x = 0, y = 0;
+    const bool inside = lp < b.n_local_pixels && local_pixel_to_xy(b, lp, x, y);
+    const bool may_see = inside && pixel_may_see_mesh(sc, b.cam, x, y);
+    for (uint32_t smp = 0; smp < b.n_samples; ++smp) {
+      const uint32_t idx = smp * b.n_local_pixels + lp;
+      bool meets = false;
+      if (inside) q.hit_obj()[idx] = RT_MISS;
+      if (may_see) {
+        PathState ps;
+        if (start_path(b, idx, ps) && meets_any_mesh(sc, ps.o, ps.d)) {
+          meets = true;
+          q.dx()[idx] = ps.d.x; q.dy()[idx] = ps.d.y; q.dz()[idx] = ps.d.z;
+        }
+      }
+      // chunk * n_samples + smp runs over as many values as the batch has chunks of paths, which is what the regions are sized for
+      const uint32_t listed = reserve_in_region(mesh.counts, region_entries, chunk * b.n_samples + smp, meets);
+      if (meets) mesh.entries[listed] = idx;
+    }
+  }
+}
+
 // Dense half of a bounce, for the paths of level k (START: level 0, recreated from their index; otherwise read
 // from `in`): the exact sphere / lone-triangle tests of the path's ray, folded with what traverse_kernel found
 // in the meshes (smaller reported t wins, the earlier object on a tie -- the order the reference's sequential
@@ -1368,7 +1423,8 @@ void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const u
 void launch_generate(const DevScene& sc, const BatchDesc& b, PathQueue q, uint32_t region_entries, MeshList mesh, hipStream_t s) {
   const size_t n = b.rays ? size_t(b.n_rays) : size_t(b.n_local_pixels) * b.n_samples;
   if (n == 0) return;
-  hipLaunchKernelGGL(generate_kernel, dim3(grid_for(n)), kBlock, 0, s, sc, b, q, region_entries, mesh);
+  if (b.rays) hipLaunchKernelGGL(generate_kernel, dim3(grid_for(n)), kBlock, 0, s, sc, b, q, region_entries, mesh);
+  else hipLaunchKernelGGL(generate_camera_kernel, dim3(grid_for(b.n_local_pixels)), kBlock, 0, s, sc, b, q, region_entries, mesh);
 }
 
 void launch_shade(const DevScene& sc, const BatchDesc& b, bool start, PathQueue in, LevelCounts in_counts, uint32_t max_in,

@@ -339,6 +339,17 @@ def test_benchmark_size_properties(ctx):
     batched, seg_b, _ = run(ssc, [P()])
     assert torch.equal(full.view(torch.int32), batched.view(torch.int32)) and seg_b == seg_full
     small.close()
+    # the one-kernel-per-bounce form of the pipeline (no per-pixel culling, no traversal lists) gives the same bits
+    import os
+    os.environ["RTMI_PIPELINE"] = "fused"
+    try:
+        fsc, _, _ = S.library_scene(ctx, scenes.scene2, width=w, height=h)
+    finally:
+        del os.environ["RTMI_PIPELINE"]
+    p8 = api.render_params(O.INT_RANDOM_WALK, depth, 8, seed=0)
+    a8, seg_a, _ = run(gsc, [p8])
+    f8, seg_f, _ = run(fsc, [p8])
+    assert torch.equal(a8.view(torch.int32), f8.view(torch.int32)) and seg_a == seg_f
     # another seed is another Monte-Carlo estimate of the same image: the mean luminance agrees within its noise
     other, _, _ = run(gsc, [api.render_params(O.INT_RANDOM_WALK, depth, spp, seed=77)])
     mean_y, mean_other = float(full.view(h, w, 3)[:, :, 1].mean()), float(other.view(h, w, 3)[:, :, 1].mean())
