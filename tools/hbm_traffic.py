@@ -8,7 +8,8 @@ from pathlib import Path
 
 prof, workload = sys.argv[1], sys.argv[2]
 out = Path(sys.argv[3] if len(sys.argv) > 3 else Path(__file__).resolve().parent.parent / "profiles" / "hbm_traffic.json")
-KERNELS = ("traverse_kernel", "shade_kernel", "bounce_kernel", "emit_kernel", "resolve_kernel")
+KERNELS = ("traverse_kernel", "shade_start_kernel", "shade_extended_kernel", "shade_kernel", "generate_camera_kernel", "generate_kernel",
+           "bounce_kernel", "emit_kernel", "resolve_kernel")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub in ("pmc_fetch", "pmc_write"):
     for f in glob.glob("%s/%s/**/*counter_collection.csv" % (prof, sub), recursive=True):

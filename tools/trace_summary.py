@@ -2,7 +2,8 @@
 """Prints per-launch durations of the last batch of path kernels from a rocprofv3 kernel trace csv."""
 import csv, glob, sys
 f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
-names = ("bounce_kernel", "generate_kernel", "shade_kernel", "traverse_kernel", "emit_kernel", "resolve_kernel")
+names = ("bounce_kernel", "generate_camera_kernel", "generate_kernel", "shade_start_kernel", "shade_extended_kernel", "shade_kernel",
+         "traverse_kernel", "emit_kernel", "resolve_kernel")
 rows = [r for r in csv.DictReader(open(f)) if any(n in r["Kernel_Name"] for n in names)]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # one batch = everything up to and including a resolve_kernel
