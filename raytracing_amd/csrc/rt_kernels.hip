@@ -863,8 +863,10 @@ __device__ __forceinline__ uint32_t reserve_by_class(uint32_t* mesh_counts, uint
 // One bounce for every path of a queue: closest hit, shading, append of the continuing paths.
 // PRIMARY: the path starts here (camera ray from the Philox jitter, or a caller ray); otherwise
 // its state comes from `in`. Used for scenes without meshes, where every lane does the same work.
+// With the extension materials compiled in, the kernel is held to 128 registers (four waves per SIMD): the few spilled
+// values cost less than the fourth wave brings.
 template <bool PRIMARY, int RULE, bool COUNT, bool EXT>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(EXT ? 4 : 1, EXT ? 4 : 8)))
 bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_counts, uint32_t region_entries,
               PathQueue out, uint32_t* __restrict__ out_counts, TraceOutputs o, TraversalCounters* counters) {
   extern __shared__ uint4 lds_dynamic[];
