@@ -861,15 +861,33 @@ __device__ __forceinline__ uint32_t reserve_by_class(uint32_t* mesh_counts, uint
 
 // ------------------------------------------------------------------------------- the fused bounce kernel
 
+// The dense kernels take their arguments as one struct and read its fields through the kernel-argument pointer
+// where they are used (scalar loads that hit the constant cache) instead of as separate by-value parameters,
+// which the compiler loads once at entry and then has to keep in -- and spill from -- the 100-odd scalar registers.
+struct BounceArgs {
+  DevScene sc; BatchDesc b; PathQueue in; const uint32_t* in_counts; uint32_t region_entries; PathQueue out;
+  uint32_t* out_counts; TraceOutputs o; TraversalCounters* counters;
+};
+typedef const __attribute__((address_space(4))) BounceArgs* BounceArgsPtr;
+
 // One bounce for every path of a queue: closest hit, shading, append of the continuing paths.
 // PRIMARY: the path starts here (camera ray from the Philox jitter, or a caller ray); otherwise
 // its state comes from `in`. Used for scenes without meshes, where every lane does the same work.
-// With the extension materials compiled in, the kernel is held to 128 registers (four waves per SIMD): the few spilled
-// values cost less than the fourth wave brings.
+// Held to 128 registers (four waves per SIMD): the standard materials need a few more than that, the extension
+// materials about 40 more, and the spilled values cost less than the fourth wave brings (measured +9 % and +6 %).
 template <bool PRIMARY, int RULE, bool COUNT, bool EXT>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(EXT ? 4 : 1, EXT ? 4 : 8)))
-bounce_kernel(DevScene sc, BatchDesc b, PathQueue in, const uint32_t* __restrict__ in_counts, uint32_t region_entries,
-              PathQueue out, uint32_t* __restrict__ out_counts, TraceOutputs o, TraversalCounters* counters) {
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
+bounce_kernel(BounceArgs a) {
+  const BounceArgsPtr ap = (BounceArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  const DevScene& sc = *(const DevScene*)&ap->sc;
+  const BatchDesc& b = *(const BatchDesc*)&ap->b;
+  const PathQueue& in = *(const PathQueue*)&ap->in;
+  const PathQueue& out = *(const PathQueue*)&ap->out;
+  const TraceOutputs& o = *(const TraceOutputs*)&ap->o;
+  const uint32_t* __restrict__ in_counts = ap->in_counts;
+  uint32_t* __restrict__ out_counts = ap->out_counts;
+  const uint32_t region_entries = ap->region_entries;
+  TraversalCounters* counters = ap->counters;
   extern __shared__ uint4 lds_dynamic[];
   __shared__ uint32_t s_chunk_prefix[kShards + 1];  // chunks of kBlock paths before each input region
   __shared__ uint32_t s_region_fill[kShards];
@@ -998,17 +1016,34 @@ generate_camera_kernel(DevScene sc, BatchDesc b, PathQueue q, uint32_t region_en
 // in the meshes (smaller reported t wins, the earlier object on a tie -- the order the reference's sequential
 // strict-'<' scan produces), hit point and normal for the winner only, shading, and the append of the
 // continuing paths to `out`. A new ray that meets a mesh's box is listed for the next traverse_kernel.
+struct ShadeArgs {
+  DevScene sc; BatchDesc b; PathQueue in; LevelCounts in_counts; uint32_t region_entries; PathQueue out;
+  LevelCounts out_counts; TraceOutputs o;
+};
+typedef const __attribute__((address_space(4))) ShadeArgs* ShadeArgsPtr;
+
 template <bool START, bool EXT>
-__device__ __forceinline__ void shade_paths(const DevScene& sc, const BatchDesc& b, const PathQueue& in, LevelCounts in_counts,
-                                            uint32_t region_entries, const PathQueue& out, LevelCounts out_counts, const TraceOutputs& o) {
+__device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
   __shared__ uint32_t s_chunk_prefix[2 * kShards + 1];
   __shared__ uint32_t s_region_fill[2 * kShards];
-  const bool deep = b.max_depth > 16;
-  const uint32_t n_start = b.rays ? b.n_rays : b.n_local_pixels * b.n_samples;
-  const uint32_t n_chunks = START ? (n_start + kBlock - 1) / kBlock
-                                  : number_chunks2(in_counts.mesh, in_counts.other, region_entries, s_chunk_prefix, s_region_fill);
+  uint32_t n_chunks;
+  {
+    const BatchDesc& b0 = *(const BatchDesc*)&ap->b;
+    const uint32_t n_start0 = b0.rays ? b0.n_rays : b0.n_local_pixels * b0.n_samples;
+    n_chunks = START ? (n_start0 + kBlock - 1) / kBlock
+                     : number_chunks2(ap->in_counts.mesh, ap->in_counts.other, ap->region_entries, s_chunk_prefix, s_region_fill);
+  }
 
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const DevScene& sc = *(const DevScene*)&ap->sc;
+    const BatchDesc& b = *(const BatchDesc*)&ap->b;
+    const PathQueue& in = *(const PathQueue*)&ap->in;
+    const PathQueue& out = *(const PathQueue*)&ap->out;
+    const TraceOutputs& o = *(const TraceOutputs*)&ap->o;
+    const LevelCounts out_counts = *(const LevelCounts*)&ap->out_counts;
+    const uint32_t region_entries = ap->region_entries;
+    const bool deep = b.max_depth > 16;
+    const uint32_t n_start = b.rays ? b.n_rays : b.n_local_pixels * b.n_samples;
     uint32_t idx;
     bool active;
     if (START) { idx = chunk * kBlock + threadIdx.x; active = idx < n_start; }
@@ -1055,26 +1090,26 @@ __device__ __forceinline__ void shade_paths(const DevScene& sc, const BatchDesc&
 
 // The reference's three material types fit in 128 registers, i.e. four waves per SIMD (measured +4 % over the three
 // the allocator settles for by itself); the variant with the extension materials needs about 170 and is left alone.
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
-shade_kernel(DevScene sc, BatchDesc b, PathQueue in, LevelCounts in_counts, uint32_t region_entries, PathQueue out,
-             LevelCounts out_counts, TraceOutputs o) {
-  shade_paths<false, false>(sc, b, in, in_counts, region_entries, out, out_counts, o);
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 4
+#endif
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_SHADE_WAVES, RT_SHADE_WAVES)))
+shade_kernel(ShadeArgs a) {
+  shade_paths<false, false>((ShadeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr());
 }
 
 #ifndef RT_START_WAVES
 #define RT_START_WAVES 4
 #endif
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_START_WAVES, RT_START_WAVES)))
-shade_start_kernel(DevScene sc, BatchDesc b, PathQueue in, LevelCounts in_counts, uint32_t region_entries, PathQueue out,
-                   LevelCounts out_counts, TraceOutputs o) {
-  shade_paths<true, false>(sc, b, in, in_counts, region_entries, out, out_counts, o);
+shade_start_kernel(ShadeArgs a) {
+  shade_paths<true, false>((ShadeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr());
 }
 
 template <bool START>
 __global__ void __launch_bounds__(kBlock)
-shade_extended_kernel(DevScene sc, BatchDesc b, PathQueue in, LevelCounts in_counts, uint32_t region_entries, PathQueue out,
-                      LevelCounts out_counts, TraceOutputs o) {
-  shade_paths<START, true>(sc, b, in, in_counts, region_entries, out, out_counts, o);
+shade_extended_kernel(ShadeArgs a) {
+  shade_paths<START, true>((ShadeArgsPtr)__builtin_amdgcn_kernarg_segment_ptr());
 }
 
 // Sparse half of a bounce: BVH traversal for the listed queue entries, by persistent waves. Each
@@ -1411,7 +1446,8 @@ void launch_primary(const DevScene& sc, const BatchDesc& b, PathQueue out, uint3
   const dim3 grid(grid_for(n));
   const size_t lds = size_t(sc.stack_entries) * kBlock * sizeof(uint32_t);
   PathQueue none{};
-  RTMI_DISPATCH(bounce_kernel, true, sc, b, none, (const uint32_t*)nullptr, region_entries, out, out_counts, o, counters);
+  const BounceArgs a{sc, b, none, nullptr, region_entries, out, out_counts, o, counters};
+  RTMI_DISPATCH(bounce_kernel, true, a);
 }
 
 void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const uint32_t* in_counts, uint32_t max_in,
@@ -1420,7 +1456,8 @@ void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const u
   if (max_in == 0) return;
   const dim3 grid(grid_for(size_t(max_in) + size_t(kShards) * kBlock));
   const size_t lds = size_t(sc.stack_entries) * kBlock * sizeof(uint32_t);
-  RTMI_DISPATCH(bounce_kernel, false, sc, b, in, in_counts, region_entries, out, out_counts, o, counters);
+  const BounceArgs a{sc, b, in, in_counts, region_entries, out, out_counts, o, counters};
+  RTMI_DISPATCH(bounce_kernel, false, a);
 }
 
 void launch_generate(const DevScene& sc, const BatchDesc& b, PathQueue q, uint32_t region_entries, MeshList mesh, hipStream_t s) {
@@ -1435,11 +1472,12 @@ void launch_shade(const DevScene& sc, const BatchDesc& b, bool start, PathQueue 
   if (max_in == 0) return;
   const dim3 grid(grid_for(size_t(max_in) + (start ? 0 : 2 * size_t(kShards) * kBlock)));
   const int sel = (start ? 2 : 0) | (sc.extension_materials ? 1 : 0);
+  const ShadeArgs a{sc, b, in, in_counts, region_entries, out, out_counts, o};
   switch (sel) {
-    case 0: hipLaunchKernelGGL(shade_kernel, grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, o); break;
-    case 1: hipLaunchKernelGGL((shade_extended_kernel<false>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, o); break;
-    case 2: hipLaunchKernelGGL(shade_start_kernel, grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, o); break;
-    default: hipLaunchKernelGGL((shade_extended_kernel<true>), grid, kBlock, 0, s, sc, b, in, in_counts, region_entries, out, out_counts, o); break;
+    case 0: hipLaunchKernelGGL(shade_kernel, grid, kBlock, 0, s, a); break;
+    case 1: hipLaunchKernelGGL((shade_extended_kernel<false>), grid, kBlock, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(shade_start_kernel, grid, kBlock, 0, s, a); break;
+    default: hipLaunchKernelGGL((shade_extended_kernel<true>), grid, kBlock, 0, s, a); break;
   }
 }
 
