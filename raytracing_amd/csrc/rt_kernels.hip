@@ -694,45 +694,41 @@ __device__ __forceinline__ Shaded shade_hit(const DevScene& sc, const BatchDesc&
           if (o.emit_counts) { r.emits = true; r.emit_info = uint32_t(m.emitted) | (hit_index << 8); }
           else { emit_sample(sc.spectra, m.emitted, s.chain, hit_index, xyz, spectrum_out); contributes = true; }
         }
-      } else if (m.type == RT_MAT_LAMBERTIAN) {  // src/scene.rs:63-79
-        if ((m.present & RT_HAS_AMBIENT) && s.remaining > 1) {
-          double r1, r2;
-          uniform_pair(b.seed, s.pixel, s.sample, hit_index, 1, r1, r2);
-          r.nd = normalize(cosine_direction(hit.n, r1, r2));
-          r.no = hit.p + hit.n * 1e-10;
-          chain_set(s.chain, hit_index, m.ambient);
-          r.alive = true;
-        }
-      } else if (EXT && m.type == RT_MAT_GLOSSY) {      // extension: Phong lobe about the mirror direction
-        if (s.remaining > 1) {
+      } else if (s.remaining > 1) {
+        // the continuing materials choose a direction, a side of the surface and a factor; the new ray is formed once
+        // for all of them, so a wave with several materials runs the normalisation once
+        V3 dir = s.d, side = hit.n;
+        uint32_t factor = (m.present & RT_HAS_SPECULAR) ? uint32_t(m.specular) : uint32_t(RT_NO_SPECTRUM);
+        bool continues = true;
+        if (m.type == RT_MAT_LAMBERTIAN) {       // src/scene.rs:63-79
+          continues = (m.present & RT_HAS_AMBIENT) != 0;
+          if (continues) {
+            double r1, r2;
+            uniform_pair(b.seed, s.pixel, s.sample, hit_index, 1, r1, r2);
+            dir = cosine_direction(hit.n, r1, r2);
+            factor = m.ambient;
+          }
+        } else if (EXT && m.type == RT_MAT_GLOSSY) {      // extension: Phong lobe about the mirror direction
           const V3 axis = normalize(s.d - hit.n * (2.0 * dot(s.d, hit.n)));
           double r1, r2;
           uniform_pair(b.seed, s.pixel, s.sample, hit_index, 1, r1, r2);
-          const V3 dir = phong_lobe_direction(axis, double(m.ns), r1, r2);
-          if (dot(dir, hit.n) > 0.0) {           // a sample under the surface is absorbed
-            r.nd = normalize(dir);
-            r.no = hit.p + hit.n * 1e-10;
-            chain_set(s.chain, hit_index, (m.present & RT_HAS_SPECULAR) ? uint32_t(m.specular) : uint32_t(RT_NO_SPECTRUM));
-            r.alive = true;
-          }
-        }
-      } else if (EXT && m.type == RT_MAT_DIELECTRIC) {  // extension: smooth dielectric with Schlick's reflectance
-        if (s.remaining > 1) {
+          dir = phong_lobe_direction(axis, double(m.ns), r1, r2);
+          continues = dot(dir, hit.n) > 0.0;     // a sample under the surface is absorbed
+        } else if (EXT && m.type == RT_MAT_DIELECTRIC) {  // extension: smooth dielectric with Schlick's reflectance
           const V3 nf = dot(hit.n, s.d) > 0.0 ? neg(hit.n) : hit.n;
           double u0, u1;
           uniform_pair(b.seed, s.pixel, s.sample, hit_index, 1, u0, u1);
-          V3 dir;
           const bool reflected = dielectric_direction(s.d, nf, entering, double(m.ni), u0, dir);
+          side = reflected ? nf : neg(nf);       // a refracted ray starts on the far side
+        } else {                                 // Specular, src/scene.rs:80-112
+          dir = s.d - hit.n * (2.0 * dot(s.d, hit.n));
+        }
+        if (continues) {
           r.nd = normalize(dir);
-          r.no = reflected ? hit.p + nf * 1e-10 : hit.p - nf * 1e-10;
-          chain_set(s.chain, hit_index, (m.present & RT_HAS_SPECULAR) ? uint32_t(m.specular) : uint32_t(RT_NO_SPECTRUM));
+          r.no = hit.p + side * 1e-10;
+          chain_set(s.chain, hit_index, factor);
           r.alive = true;
         }
-      } else if (s.remaining > 1) {              // Specular, src/scene.rs:80-112
-        r.nd = normalize(s.d - hit.n * (2.0 * dot(s.d, hit.n)));
-        r.no = hit.p + hit.n * 1e-10;
-        chain_set(s.chain, hit_index, (m.present & RT_HAS_SPECULAR) ? uint32_t(m.specular) : uint32_t(RT_NO_SPECTRUM));
-        r.alive = true;
       }
     }
   }
