@@ -23,19 +23,20 @@ struct PathQueue {
 #define RTMI_Q_ARRAY(T, name, offset_bytes_per_entry) \
   T* name() const { return reinterpret_cast<T*>(base + entries * uint64_t(offset_bytes_per_entry)); }
 #endif
-  RTMI_Q_ARRAY(double, ox, 0) RTMI_Q_ARRAY(double, oy, 8) RTMI_Q_ARRAY(double, oz, 16)
-  RTMI_Q_ARRAY(double, dx, 24) RTMI_Q_ARRAY(double, dy, 32) RTMI_Q_ARRAY(double, dz, 40)
-  RTMI_Q_ARRAY(uint32_t, pixel, 48)       // y * width + x : Philox counter word 0
-  RTMI_Q_ARRAY(uint32_t, sample, 52)      // Philox counter word 1
-  RTMI_Q_ARRAY(uint32_t, slot, 56)        // where this path's contribution goes
-  RTMI_Q_ARRAY(uint32_t, remaining, 60)   // ray casts the path may still make (the reference's `iteraciones`)
-  // closest mesh hit of the entry's ray, used by the two-kernel pipeline: cleared when the entry is created,
-  // filled in by traverse_kernel. hit_obj == RT_MISS: no mesh was hit.
-  RTMI_Q_ARRAY(double, hit_t, 64)         // t as the reference reports it (what objects are compared by)
-  RTMI_Q_ARRAY(double, hit_raw, 72)       // Moller-Trumbore's t along the re-normalised ray (places the hit point)
-  RTMI_Q_ARRAY(uint32_t, hit_obj, 80)
-  RTMI_Q_ARRAY(uint32_t, hit_prim, 84)    // file-order triangle index
-  RTMI_Q_ARRAY(uint32_t, hit_slot, 88)    // position of that triangle in leaf order
+  // fields that are read and written together share 16-byte elements: one address and one memory instruction each
+  RTMI_Q_ARRAY(double2, o_xy, 0)          // origin x, y
+  RTMI_Q_ARRAY(double2, oz_dx, 16)        // origin z, direction x
+  RTMI_Q_ARRAY(double2, d_yz, 32)         // direction y, z
+  // x = y * width + x of the pixel (Philox counter word 0), y = sample (Philox counter word 1), z = slot (where this
+  // path's contribution goes), w = ray casts the path may still make (the reference's `iteraciones`)
+  RTMI_Q_ARRAY(uint4, ids, 48)
+  // closest mesh hit of the entry's ray, used by the two-kernel pipeline: hit_obj is cleared when the entry is
+  // created (RT_MISS: no mesh was hit), the rest is filled in by traverse_kernel.
+  // x = t as the reference reports it (what objects are compared by), y = Moller-Trumbore's t along the re-normalised
+  // ray (places the hit point)
+  RTMI_Q_ARRAY(double2, hit_t_raw, 64)
+  RTMI_Q_ARRAY(uint2, hit_prim_slot, 80)  // file-order triangle index, position of that triangle in leaf order
+  RTMI_Q_ARRAY(uint32_t, hit_obj, 88)
   RTMI_Q_ARRAY(uint4, chain0, 92)         // spectrum-table rows picked up at hits 0..15, one byte each (92 E is a multiple of 16: E is one of 64)
   RTMI_Q_ARRAY(uint4, chain1, 108)        // hits 16..31, only when deep
 #undef RTMI_Q_ARRAY

@@ -538,9 +538,8 @@ __device__ __forceinline__ bool dielectric_direction(V3 i, V3 nf, bool entering,
 
 __device__ __forceinline__ void queue_store(const PathQueue& q, uint32_t at, V3 o, V3 d, uint32_t pixel, uint32_t sample,
                                             uint32_t slot, uint32_t remaining, const Chain& chain, bool deep) {
-  q.ox()[at] = o.x; q.oy()[at] = o.y; q.oz()[at] = o.z;
-  q.dx()[at] = d.x; q.dy()[at] = d.y; q.dz()[at] = d.z;
-  q.pixel()[at] = pixel; q.sample()[at] = sample; q.slot()[at] = slot; q.remaining()[at] = remaining;
+  q.o_xy()[at] = make_double2(o.x, o.y); q.oz_dx()[at] = make_double2(o.z, d.x); q.d_yz()[at] = make_double2(d.y, d.z);
+  q.ids()[at] = make_uint4(pixel, sample, slot, remaining);
   q.chain0()[at] = chain.a;
   if (deep) q.chain1()[at] = chain.b;
 }
@@ -641,9 +640,11 @@ __device__ __forceinline__ bool start_path(const BatchDesc& b, uint32_t idx, Pat
 }
 
 __device__ __forceinline__ void load_path(const PathQueue& q, uint32_t idx, bool deep, PathState& s) {
-  s.o = mk(q.ox()[idx], q.oy()[idx], q.oz()[idx]);
-  s.d = mk(q.dx()[idx], q.dy()[idx], q.dz()[idx]);
-  s.pixel = q.pixel()[idx]; s.sample = q.sample()[idx]; s.slot = q.slot()[idx]; s.remaining = q.remaining()[idx];
+  const double2 o_xy = q.o_xy()[idx], oz_dx = q.oz_dx()[idx], d_yz = q.d_yz()[idx];
+  s.o = mk(o_xy.x, o_xy.y, oz_dx.x);
+  s.d = mk(oz_dx.y, d_yz.x, d_yz.y);
+  const uint4 ids = q.ids()[idx];
+  s.pixel = ids.x; s.sample = ids.y; s.slot = ids.z; s.remaining = ids.w;
   s.chain.a = q.chain0()[idx];
   s.chain.b = deep ? q.chain1()[idx] : make_uint4(0, 0, 0, 0);
 }
@@ -943,8 +944,8 @@ generate_kernel(DevScene sc, BatchDesc b, PathQueue q, uint32_t region_entries, 
       PathState ps;
       if (start_path(b, idx, ps) && meets_any_mesh(sc, ps.o, ps.d)) {
         meets = true;
-        q.dx()[idx] = ps.d.x; q.dy()[idx] = ps.d.y; q.dz()[idx] = ps.d.z;
-        if (b.rays) { q.ox()[idx] = ps.o.x; q.oy()[idx] = ps.o.y; q.oz()[idx] = ps.o.z; }
+        q.oz_dx()[idx] = make_double2(ps.o.z, ps.d.x); q.d_yz()[idx] = make_double2(ps.d.y, ps.d.z);
+        if (b.rays) q.o_xy()[idx] = make_double2(ps.o.x, ps.o.y);
       }
     }
     const uint32_t listed = reserve_in_region(mesh.counts, region_entries, chunk, meets);
@@ -997,7 +998,7 @@ generate_camera_kernel(DevScene sc, BatchDesc b, PathQueue q, uint32_t region_en
         PathState ps;
         if (start_path(b, idx, ps) && meets_any_mesh(sc, ps.o, ps.d)) {
           meets = true;
-          q.dx()[idx] = ps.d.x; q.dy()[idx] = ps.d.y; q.dz()[idx] = ps.d.z;
+          q.oz_dx()[idx] = make_double2(ps.o.z, ps.d.x); q.d_yz()[idx] = make_double2(ps.d.y, ps.d.z);
         }
       }
       // chunk * n_samples + smp runs over as many values as the batch has chunks of paths, which is what the regions are sized for
@@ -1063,10 +1064,11 @@ __device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
       uint32_t tri_slot = 0;
       const uint32_t mesh_obj = sc.n_meshes ? in.hit_obj()[idx] : RT_MISS;
       if (mesh_obj != RT_MISS) {
-        const double mesh_t = in.hit_t()[idx];
-        if (pre.obj == RT_MISS || mesh_t < pre.t || (mesh_t == pre.t && mesh_obj < pre.obj)) {
-          hit.obj = mesh_obj; hit.t = mesh_t; hit.prim = in.hit_prim()[idx];
-          t_raw = in.hit_raw()[idx]; tri_slot = in.hit_slot()[idx];
+        const double2 mesh_t = in.hit_t_raw()[idx];
+        if (pre.obj == RT_MISS || mesh_t.x < pre.t || (mesh_t.x == pre.t && mesh_obj < pre.obj)) {
+          const uint2 which = in.hit_prim_slot()[idx];
+          hit.obj = mesh_obj; hit.t = mesh_t.x; hit.prim = which.x;
+          t_raw = mesh_t.y; tri_slot = which.y;
         }
       }
       const bool found = hit.obj != RT_MISS;
@@ -1190,8 +1192,8 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
       }
       if (++m == sc.n_meshes) {
         if (best_obj != RT_MISS) {   // shade_kernel folds this with the spheres and lone triangles
-          q.hit_t()[entry] = best_t; q.hit_raw()[entry] = best_raw; q.hit_obj()[entry] = best_obj;
-          q.hit_prim()[entry] = best_prim; q.hit_slot()[entry] = best_slot;
+          q.hit_t_raw()[entry] = make_double2(best_t, best_raw); q.hit_obj()[entry] = best_obj;
+          q.hit_prim_slot()[entry] = make_uint2(best_prim, best_slot);
         }
         entry = RT_MISS;
       }
@@ -1203,8 +1205,10 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
         const uint32_t region = find_region(s_prefix, g);
         entry = region * region_entries + (g - s_prefix[region]);   // the mesh class of a level sits at the front of its regions
         if (mesh.entries) entry = mesh.entries[entry];               // level 0: positions of the listed primary rays
-        o = origin.fixed ? mk(origin.x, origin.y, origin.z) : mk(q.ox()[entry], q.oy()[entry], q.oz()[entry]);
-        dn = normalize(mk(q.dx()[entry], q.dy()[entry], q.dz()[entry]));  // src/geometry/ray.rs:45
+        const double2 oz_dx = q.oz_dx()[entry], d_yz = q.d_yz()[entry];
+        if (origin.fixed) o = mk(origin.x, origin.y, origin.z);
+        else { const double2 o_xy = q.o_xy()[entry]; o = mk(o_xy.x, o_xy.y, oz_dx.x); }
+        dn = normalize(mk(oz_dx.y, d_yz.x, d_yz.y));  // src/geometry/ray.rs:45
         m = 0; best_obj = RT_MISS;
       }
       const uint32_t taken = uint32_t(__popcll(idle));
