@@ -831,16 +831,31 @@ __device__ __forceinline__ uint32_t number_chunks2(const uint32_t* __restrict__ 
   return s_prefix[2 * kShards];
 }
 
-__device__ __forceinline__ bool queue_position2(const uint32_t* s_prefix, const uint32_t* s_fill, uint32_t region_entries,
-                                                uint32_t chunk, uint32_t& idx) {
-  uint32_t lo = 0, hi = 2 * kShards;
-  while (hi - lo > 1) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (s_prefix[mid] <= chunk) lo = mid; else hi = mid;
-  }
-  const uint32_t within = (chunk - s_prefix[lo]) * kBlock + threadIdx.x;
-  idx = lo < kShards ? lo * region_entries + within : (lo - kShards) * region_entries + (region_entries - 1u - within);
-  return within < s_fill[lo];
+// The 2 * kShards prefix and fill values, two of each per lane of a wave: the pseudo-region of a chunk is then found
+// with two wave-wide comparisons instead of a binary search through LDS.
+struct ChunkMap { uint32_t prefix_lo, prefix_hi, fill_lo, fill_hi; };
+
+__device__ __forceinline__ ChunkMap load_chunk_map(const uint32_t* s_prefix, const uint32_t* s_fill) {
+  const uint32_t lane = threadIdx.x % 64;
+  ChunkMap m;
+  m.prefix_lo = s_prefix[lane]; m.prefix_hi = s_prefix[kShards + lane];
+  m.fill_lo = s_fill[lane]; m.fill_hi = s_fill[kShards + lane];
+  return m;
+}
+
+// chunk (the same for the whole wave, all of whose lanes must be here) -> the lane's queue entry
+__device__ __forceinline__ bool queue_position2(const ChunkMap& m, uint32_t region_entries, uint32_t chunk, uint32_t& idx) {
+  static_assert(kShards == 64, "one prefix value of each class per lane");
+  // the last pseudo-region whose first chunk is <= chunk: prefixes never decrease and the first is 0
+  const uint32_t at_or_before = uint32_t(__popcll(__ballot(m.prefix_lo <= chunk))) + uint32_t(__popcll(__ballot(m.prefix_hi <= chunk)));
+  const int lo = __builtin_amdgcn_readfirstlane(int(at_or_before) - 1);
+  const bool other = lo >= int(kShards);
+  const int holder = other ? lo - int(kShards) : lo;
+  const uint32_t first = uint32_t(__builtin_amdgcn_readlane(int(other ? m.prefix_hi : m.prefix_lo), holder));
+  const uint32_t fill = uint32_t(__builtin_amdgcn_readlane(int(other ? m.fill_hi : m.fill_lo), holder));
+  const uint32_t within = (chunk - first) * kBlock + threadIdx.x;
+  idx = other ? uint32_t(holder) * region_entries + (region_entries - 1u - within) : uint32_t(holder) * region_entries + within;
+  return within < fill;
 }
 
 // Reserves a place for the lane's path in region chunk % kShards, in the mesh class (from the front) or the other
@@ -1031,6 +1046,8 @@ __device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
                      : number_chunks2(ap->in_counts.mesh, ap->in_counts.other, ap->region_entries, s_chunk_prefix, s_region_fill);
   }
 
+  const ChunkMap chunk_map = START ? ChunkMap{0, 0, 0, 0} : load_chunk_map(s_chunk_prefix, s_region_fill);
+
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const DevScene& sc = *(const DevScene*)&ap->sc;
     const BatchDesc& b = *(const BatchDesc*)&ap->b;
@@ -1044,7 +1061,7 @@ __device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
     uint32_t idx;
     bool active;
     if (START) { idx = chunk * kBlock + threadIdx.x; active = idx < n_start; }
-    else active = queue_position2(s_chunk_prefix, s_region_fill, region_entries, chunk, idx);
+    else active = queue_position2(chunk_map, region_entries, chunk, idx);
     PathState ps;
     ps.o = mk(0, 0, 0); ps.d = mk(1, 0, 0); ps.pixel = ps.sample = ps.slot = ps.remaining = 0;
     ps.chain.a = make_uint4(0, 0, 0, 0); ps.chain.b = make_uint4(0, 0, 0, 0);
