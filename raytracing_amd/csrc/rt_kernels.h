@@ -61,6 +61,19 @@ inline size_t queue_entries(size_t max_paths) { return size_t(region_chunks(max_
 
 // One batch of primary paths: samples [sample0, sample0+n_samples) of the pixels of a run of
 // tiles. Path slot = sample_local * n_local_pixels + local_pixel.
+// n / d for a divisor fixed at launch: one 32 x 32 -> 64 multiply and a shift instead of the two dozen instructions
+// of a division by a run-time value. Exact for n < 2^31 and 1 <= d <= 2^30 (path and pixel indices stay below 2^30):
+// m = floor(2^shift / d) + 1 with shift = 31 + ceil(log2 d), which always fits 32 bits.
+struct FastDiv { uint32_t d, m, shift, pad; };
+inline FastDiv make_fast_div(uint32_t d) {
+  if (d == 0) d = 1;
+  uint32_t s = 0;
+  while ((1ull << s) < d) ++s;
+  FastDiv f{d, 0, 31 + s, 0};
+  f.m = uint32_t((1ull << f.shift) / d + 1);
+  return f;
+}
+
 struct BatchDesc {
   DevCamera cam;
   const uint32_t* tile_list;   // tile ids (x-major) this batch covers, device memory
@@ -68,6 +81,7 @@ struct BatchDesc {
   uint32_t tile_size;          // multiple of 8
   uint32_t tiles_y;            // tiles per image column
   uint32_t n_local_pixels;     // n_tiles * tile_size^2 (includes pixels clipped off the image)
+  FastDiv by_local_pixels, by_tile_pixels, by_tiles_y, by_blocks_per_row;   // n_local_pixels, tile_size^2, tiles_y, tile_size / 8
   uint32_t sample0, n_samples;
   uint32_t integrator, max_depth;
   uint64_t seed;

@@ -547,14 +547,17 @@ __device__ __forceinline__ void queue_store(const PathQueue& q, uint32_t at, V3 
 // local pixel of a batch -> image coordinates. Tiles are numbered x-major as the reference
 // enumerates them (src/integrators/integrator.rs:50); inside a tile, 64 consecutive local
 // pixels are one 8x8 block, so the primary rays of a wave stay together.
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv& f) { return uint32_t((uint64_t(n) * f.m) >> f.shift); }
+
 __device__ __forceinline__ bool local_pixel_to_xy(const BatchDesc& b, uint32_t lp, uint32_t& x, uint32_t& y) {
-  const uint32_t per_tile = b.tile_size * b.tile_size;
-  const uint32_t tile = b.tile_list[lp / per_tile];
-  const uint32_t within = lp % per_tile;
-  const uint32_t blocks_per_row = b.tile_size / kPixelBlock;
+  const uint32_t tile_index = fast_div(lp, b.by_tile_pixels);
+  const uint32_t tile = b.tile_list[tile_index];
+  const uint32_t within = lp - tile_index * b.by_tile_pixels.d;
   const uint32_t block = within / (kPixelBlock * kPixelBlock), in_block = within % (kPixelBlock * kPixelBlock);
-  x = (tile / b.tiles_y) * b.tile_size + (block % blocks_per_row) * kPixelBlock + (in_block % kPixelBlock);
-  y = (tile % b.tiles_y) * b.tile_size + (block / blocks_per_row) * kPixelBlock + (in_block / kPixelBlock);
+  const uint32_t tile_x = fast_div(tile, b.by_tiles_y), tile_y = tile - tile_x * b.by_tiles_y.d;
+  const uint32_t block_y = fast_div(block, b.by_blocks_per_row), block_x = block - block_y * b.by_blocks_per_row.d;
+  x = tile_x * b.tile_size + block_x * kPixelBlock + (in_block % kPixelBlock);
+  y = tile_y * b.tile_size + block_y * kPixelBlock + (in_block / kPixelBlock);
   return x < b.cam.width && y < b.cam.height;
 }
 
@@ -623,8 +626,9 @@ __device__ __forceinline__ bool start_path(const BatchDesc& b, uint32_t idx, Pat
     s.pixel = b.pixel_base + idx; s.sample = b.sample0;
     return true;
   }
-  const uint32_t lp = idx % b.n_local_pixels;
-  s.sample = b.sample0 + idx / b.n_local_pixels;
+  const uint32_t sample_local = fast_div(idx, b.by_local_pixels);
+  const uint32_t lp = idx - sample_local * b.n_local_pixels;
+  s.sample = b.sample0 + sample_local;
   uint32_t x, y;
   if (!local_pixel_to_xy(b, lp, x, y)) return false;
   s.pixel = y * b.cam.width + x;

@@ -760,6 +760,8 @@ extern "C" int rtmi_render_accumulate(rtmi_scene* s, const rtmi_camera* cam, con
       b.cam = to_dev_camera(*cam);
       b.tile_list = ctx->tiles.as<uint32_t>() + t0; b.n_tiles = nt; b.tile_size = T; b.tiles_y = tiles_y;
       b.n_local_pixels = uint32_t(nt * per_tile);
+      b.by_local_pixels = make_fast_div(b.n_local_pixels); b.by_tile_pixels = make_fast_div(uint32_t(per_tile));
+      b.by_tiles_y = make_fast_div(tiles_y); b.by_blocks_per_row = make_fast_div(T / kPixelBlock);
       b.sample0 = s0; b.n_samples = std::min(samples_per_batch, s_end - s0);
       b.integrator = p->integrator; b.max_depth = p->max_depth; b.seed = p->seed;
       const size_t n_paths = size_t(b.n_local_pixels) * b.n_samples;
