@@ -32,7 +32,9 @@ extern "C" {
 #define RTMI_MAX_DEPTH 32      /* longest path (ray casts per path) the kernels carry state for */
 
 typedef enum {
-  RTMI_OK = 0, RTMI_BAD_ARG = -1, RTMI_NO_DEVICE = -2, RTMI_OOM = -3, RTMI_HIP_ERROR = -4, RTMI_UNSUPPORTED = -5
+  RTMI_OK = 0, RTMI_BAD_ARG = -1, RTMI_NO_DEVICE = -2, RTMI_OOM = -3, RTMI_HIP_ERROR = -4, RTMI_UNSUPPORTED = -5,
+  RTMI_RCCL_ERROR = -6,  /* the collective library could not be loaded, or one of its calls failed */
+  RTMI_INTERNAL = -7     /* a consistency check inside the library failed; the output of the call is not valid */
 } rtmi_status;
 
 /* enum Shape (src/shapes/shape.rs:34-39); BoxAABB is never built by any loader and is not carried */

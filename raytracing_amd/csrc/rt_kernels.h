@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "rt_types.h"
 #include "spectrum.h"
 
@@ -49,15 +51,25 @@ constexpr uint32_t kPixelBlock = 8;    // a wave covers an 8x8 pixel block of it
 // A queue is split into kShards regions, each with its own fill counter on its own 128-byte
 // line: one returning atomic per wave on a single word saturates at about 90 atomics per
 // microsecond chip-wide, which capped the whole kernel. Work is dealt in chunks of kBlock
-// paths; the survivors of chunk c go to region c % kShards. A region can never overflow:
-// it receives at most ceil(total_chunks / kShards) chunks of at most kBlock survivors each.
+// paths; the survivors of chunk c go to region c % kShards, so a region receives at most
+// ceil(C / kShards) chunks of at most kBlock survivors each, where C bounds the chunk numbers a
+// kernel can deal. C exceeds ceil(paths / kBlock) by the partial chunks of the producer's input:
+//   - one per region of a fused-pipeline level (kShards),
+//   - one per region and class of a two-kernel-pipeline level (2 * kShards),
+//   - one per sample of a camera batch for the level-0 mesh list, whose chunks are numbered
+//     (pixel chunk) * n_samples + sample (`slack_chunks` carries that term).
+// The second word of every counter line is an overflow flag: a wave that is handed a position past
+// its region's end sets it and drops the path instead of writing outside the region.
 constexpr uint32_t kShards = 64;
 constexpr uint32_t kCountStride = 32;  // in uint32 units: one counter per 128-byte line
-inline uint32_t region_chunks(size_t max_paths) {
-  const size_t chunks = (max_paths + kBlock - 1) / kBlock + kShards;
+constexpr uint32_t kOverflowWord = 1;  // word of a counter line that flags an overflow of its region
+inline uint32_t region_chunks(size_t max_paths, size_t slack_chunks = 0) {
+  const size_t chunks = (max_paths + kBlock - 1) / kBlock + std::max<size_t>(2 * kShards, slack_chunks);
   return uint32_t((chunks + kShards - 1) / kShards);
 }
-inline size_t queue_entries(size_t max_paths) { return size_t(region_chunks(max_paths)) * kBlock * kShards; }
+inline size_t queue_entries(size_t max_paths, size_t slack_chunks = 0) {
+  return size_t(region_chunks(max_paths, slack_chunks)) * kBlock * kShards;
+}
 
 // One batch of primary paths: samples [sample0, sample0+n_samples) of the pixels of a run of
 // tiles. Path slot = sample_local * n_local_pixels + local_pixel.
@@ -114,7 +126,8 @@ struct TraceOutputs {
 // nodes / node_slots etc. give the lane occupancy of each phase.
 struct TraversalCounters { unsigned long long nodes, prims, node_slots, prim_slots, service_slots, service_lanes; };
 
-void upload_constants(const SpectrumTables& t);
+// copies the spectral tables into the current device's constant memory
+hipError_t upload_constants(const SpectrumTables& t);
 
 // Bounce 0: generates the camera rays of the batch (or reads caller rays), finds the closest
 // hit, shades, and appends surviving paths to `out`. out_counts: kShards counters, kCountStride
@@ -161,6 +174,10 @@ void launch_intersect(const DevScene& sc, const void* rays, size_t n, void* hits
 void launch_resolve(const BatchDesc& b, TraceOutputs o, float* xyz_sum, hipStream_t s);
 // *total += every fill counter of n_levels consecutive queue levels
 void launch_sum_counts(const uint32_t* counts, uint32_t n_levels, unsigned long long* total, hipStream_t s);
+// *flag = 1 when a region of the first n_levels queue levels flagged an overflow, or when the two classes of a region
+// (level k and level pair_level0 + k, k < n_pairs) together hold more than region_entries paths
+void launch_check_overflow(const uint32_t* counts, uint32_t n_levels, uint32_t pair_level0, uint32_t n_pairs,
+                           uint32_t region_entries, uint32_t* flag, hipStream_t s);
 void launch_tonemap(const float* xyz_sum, uint32_t spp, uint32_t n_pixels, uint8_t* rgb8, hipStream_t s);
 
 }  // namespace rtmi

@@ -32,10 +32,11 @@ __constant__ float c_cie[3][RT_NBINS];
 __constant__ float c_smits_refl[7][RT_NBINS];
 __constant__ float c_xyz_scale;
 
-void upload_constants(const SpectrumTables& t) {
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_cie), t.cie, sizeof t.cie);
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_smits_refl), t.smits[0], sizeof t.smits[0]);
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(c_xyz_scale), &t.xyz_scale, sizeof(float));
+hipError_t upload_constants(const SpectrumTables& t) {
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_cie), t.cie, sizeof t.cie);
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_smits_refl), t.smits[0], sizeof t.smits[0]);
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_xyz_scale), &t.xyz_scale, sizeof(float));
+  return e;
 }
 
 namespace {
@@ -227,6 +228,47 @@ __device__ __forceinline__ bool meets_box(const DevObject& ob, V3 o, const RayDi
   return slab32(ob.box_lo, ob.box_hi, br, INFINITY, tn);
 }
 
+// ModelObj::intersect's own box test (src/shapes/model_obj.rs:78 -> src/geometry/aabb.rs:136-247), exactly as the
+// reference evaluates it: the ray as it was built (direction normalised once, at Ray::new), binary64 quotients, the
+// interval starting at [0, inf), a zero direction component decided by containment. A model whose box the ray fails
+// reports no hit, whatever Moller-Trumbore would say about a triangle that touches the box's surface.
+__device__ __forceinline__ bool model_gate_exact(const double* lo, const double* hi, V3 o, V3 d) {
+  const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+  double t_lo = 0.0, t_hi = INFINITY;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (dd[k] == 0.0) {
+      if (oo[k] < lo[k] || oo[k] > hi[k]) return false;
+    } else {
+      const double t0 = (lo[k] - oo[k]) / dd[k], t1 = (hi[k] - oo[k]) / dd[k];
+      const double t_min = dd[k] > 0.0 ? t0 : t1, t_max = dd[k] > 0.0 ? t1 : t0;
+      if (t_min > t_lo) t_lo = t_min;
+      if (t_max < t_hi) t_hi = t_max;
+      if (t_lo > t_hi) return false;
+    }
+  }
+  return true;
+}
+
+// Does the ray certainly pass that test? It does when its binary32 image crosses the model's inner box shrunk further
+// by four times the ray's own delta: the slack this leaves in every slab interval (margin / |d_k|) exceeds both the
+// binary32 errors of this test and the rounding of the exact binary64 quotients, which scale the same way. Directions
+// with a (near-)zero component are left to the exact test.
+__device__ __forceinline__ bool model_gate_certain(const DevObject& ob, const BoxRay& r) {
+  if (!(fabsf(r.dx) > 1e-18f && fabsf(r.dy) > 1e-18f && fabsf(r.dz) > 1e-18f)) return false;
+  const float m = 4.0f * r.delta;
+  const float ax = ((ob.inner_lo[0] + m) - r.ox) * r.ix, bx = ((ob.inner_hi[0] - m) - r.ox) * r.ix;
+  const float ay = ((ob.inner_lo[1] + m) - r.oy) * r.iy, by = ((ob.inner_hi[1] - m) - r.oy) * r.iy;
+  const float az = ((ob.inner_lo[2] + m) - r.oz) * r.iz, bz = ((ob.inner_hi[2] - m) - r.oz) * r.iz;
+  // an inner box turned inside out by the margins (a flat model) has min > max on that axis and can never pass: the
+  // comparisons below are ordered ones, which a NaN also fails
+  if (!(ob.inner_lo[0] + m < ob.inner_hi[0] - m && ob.inner_lo[1] + m < ob.inner_hi[1] - m && ob.inner_lo[2] + m < ob.inner_hi[2] - m))
+    return false;
+  const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+  const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+  return tn <= tf;
+}
+
 struct MeshHit { double t, t_raw; uint32_t index; uint32_t slot; };
 
 // Closest hit inside one mesh through its BVH. RULE = RT_HIT_FIRST_INDEX returns the hit
@@ -240,10 +282,11 @@ struct MeshHit { double t, t_raw; uint32_t index; uint32_t slot; };
 // once per leaf a lane visits instead of once per node step of the slowest lane.
 template <int RULE, bool COUNT>
 __device__ __forceinline__ bool mesh_closest(const uint4* __restrict__ nodes, const DevMeshTri* __restrict__ tris,
-                                             const DevTriFrame* __restrict__ frames, const DevObject& ob, V3 o, V3 d,
+                                             const DevTriFrame* __restrict__ frames, const DevObject& ob, V3 o, V3 d_built, V3 d,
                                              uint32_t* stack, MeshHit& best, uint32_t& n_nodes, uint32_t& n_prims) {
   const BoxRay br = make_box_ray(o, d, ob);
   best.t = INFINITY; best.t_raw = 0.0; best.index = RT_MISS; best.slot = 0;
+  if (!model_gate_certain(ob, br) && !model_gate_exact(ob.gate_lo, ob.gate_hi, o, d_built)) return false;
   constexpr uint32_t kDone = RT_REF_NONE;  // has the leaf bit set, so it also ends the node loop
   uint32_t cur = 0;
   int sp = 0;
@@ -347,7 +390,7 @@ __device__ __forceinline__ bool closest_hit(const DevScene& sc, const uint4* __r
       ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, tr.frame.len, t_raw, t);
     } else {
       MeshHit mh;
-      ok = mesh_closest<RULE, COUNT>(node_words + size_t(ob.root) * 4, sc.mesh_tris + ob.first, sc.mesh_frames + ob.first, ob, o, dn, stack, mh,
+      ok = mesh_closest<RULE, COUNT>(node_words + size_t(ob.root) * 4, sc.mesh_tris + ob.first, sc.mesh_frames + ob.first, ob, o, d, dn, stack, mh,
                                      n_nodes, n_prims);
       t = mh.t; t_raw = mh.t_raw; prim = mh.index; slot = mh.slot;
     }
@@ -776,18 +819,30 @@ __device__ __forceinline__ void append_emit(const DevScene& sc, const TraceOutpu
 
 // Wave-level compaction of the lanes with `take` set into region chunk % kShards of a sharded
 // list: one ballot, one atomic per wave, takers packed in lane order. Returns the position the
-// lane's element goes to (RT_MISS for a lane that does not take part). Must be reached by all
-// lanes of the wave.
-__device__ __forceinline__ uint32_t reserve_in_region(uint32_t* counts, uint32_t region_entries, uint32_t chunk, bool take) {
+// lane's element goes to inside its region (RT_MISS for a lane that does not take part). The regions
+// are sized so that a position past the region's end cannot occur; should it, the wave flags the
+// region and the lanes past the end are told RT_MISS, so nothing is ever written outside a region.
+// Must be reached by all lanes of the wave.
+__device__ __forceinline__ uint32_t reserve_offset(uint32_t* counts, uint32_t region_entries, uint32_t chunk, bool take) {
   const unsigned long long mask = __ballot(take);
   if (!mask) return RT_MISS;
   const uint32_t lane = __lane_id();
   const uint32_t leader = uint32_t(__ffsll((long long)mask)) - 1u;
   const uint32_t region = chunk % kShards;
   uint32_t start = 0;
-  if (lane == leader) start = atomicAdd(counts + region * kCountStride, uint32_t(__popcll(mask)));
+  if (lane == leader) {
+    const uint32_t want = uint32_t(__popcll(mask));
+    start = atomicAdd(counts + region * kCountStride, want);
+    if (start + want > region_entries) counts[region * kCountStride + kOverflowWord] = 1u;
+  }
   start = __shfl(start, int(leader));
-  return take ? region * region_entries + start + uint32_t(__popcll(mask & ((1ull << lane) - 1ull))) : RT_MISS;
+  const uint32_t within = start + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+  return take && within < region_entries ? within : RT_MISS;
+}
+
+__device__ __forceinline__ uint32_t reserve_in_region(uint32_t* counts, uint32_t region_entries, uint32_t chunk, bool take) {
+  const uint32_t within = reserve_offset(counts, region_entries, chunk, take);
+  return within == RT_MISS ? RT_MISS : (chunk % kShards) * region_entries + within;
 }
 
 // COUNT builds: adds 64 to `w` once per wave-level execution of the place it is called from
@@ -863,16 +918,16 @@ __device__ __forceinline__ bool queue_position2(const ChunkMap& m, uint32_t regi
 }
 
 // Reserves a place for the lane's path in region chunk % kShards, in the mesh class (from the front) or the other
-// class (from the back). A region cannot overflow: both classes together receive at most the survivors of the
-// chunks that feed it. Must be reached by all lanes of the wave.
+// class (from the back). Both classes together receive at most the survivors of the chunks that feed the region,
+// which is what it is sized for. Must be reached by all lanes of the wave.
 __device__ __forceinline__ uint32_t reserve_by_class(uint32_t* mesh_counts, uint32_t* other_counts, uint32_t region_entries,
                                                      uint32_t chunk, bool alive, bool meets_mesh) {
-  const uint32_t front = reserve_in_region(mesh_counts, region_entries, chunk, alive && meets_mesh);
-  const uint32_t back = reserve_in_region(other_counts, region_entries, chunk, alive && !meets_mesh);
-  if (!alive) return RT_MISS;
-  if (meets_mesh) return front;
+  const uint32_t front = reserve_offset(mesh_counts, region_entries, chunk, alive && meets_mesh);
+  const uint32_t back = reserve_offset(other_counts, region_entries, chunk, alive && !meets_mesh);
+  const uint32_t within = meets_mesh ? front : back;
+  if (!alive || within == RT_MISS) return RT_MISS;
   const uint32_t region = chunk % kShards;
-  return region * region_entries + (region_entries - 1u - (back - region * region_entries));
+  return region * region_entries + (meets_mesh ? within : region_entries - 1u - within);
 }
 
 // ------------------------------------------------------------------------------- the fused bounce kernel
@@ -936,7 +991,7 @@ bounce_kernel(BounceArgs a) {
     }
     append_emit(sc, o, chunk, deep, sh.emits, sh.emit_info, ps.slot, ps.chain);
     const uint32_t at = reserve_in_region(out_counts, region_entries, chunk, sh.alive);
-    if (sh.alive) queue_store(out, at, sh.no, sh.nd, ps.pixel, ps.sample, ps.slot, ps.remaining - 1, ps.chain, deep);
+    if (at != RT_MISS) queue_store(out, at, sh.no, sh.nd, ps.pixel, ps.sample, ps.slot, ps.remaining - 1, ps.chain, deep);
   }
 
   if (COUNT) {
@@ -968,7 +1023,7 @@ generate_kernel(DevScene sc, BatchDesc b, PathQueue q, uint32_t region_entries, 
       }
     }
     const uint32_t listed = reserve_in_region(mesh.counts, region_entries, chunk, meets);
-    if (meets) mesh.entries[listed] = idx;
+    if (listed != RT_MISS) mesh.entries[listed] = idx;
   }
 }
 
@@ -1022,7 +1077,7 @@ generate_camera_kernel(DevScene sc, BatchDesc b, PathQueue q, uint32_t region_en
       }
       // chunk * n_samples + smp runs over as many values as the batch has chunks of paths, which is what the regions are sized for
       const uint32_t listed = reserve_in_region(mesh.counts, region_entries, chunk * b.n_samples + smp, meets);
-      if (meets) mesh.entries[listed] = idx;
+      if (listed != RT_MISS) mesh.entries[listed] = idx;
     }
   }
 }
@@ -1100,7 +1155,7 @@ __device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
     append_emit(sc, o, chunk, deep, sh.emits, sh.emit_info, ps.slot, ps.chain);
     const bool meets_mesh = sh.alive && meets_any_mesh(sc, sh.no, sh.nd);
     const uint32_t at = reserve_by_class(out_counts.mesh, out_counts.other, region_entries, chunk, sh.alive, meets_mesh);
-    if (sh.alive) {
+    if (at != RT_MISS) {
       queue_store(out, at, sh.no, sh.nd, ps.pixel, ps.sample, ps.slot, ps.remaining - 1, ps.chain, deep);
       out.hit_obj()[at] = RT_MISS;
     }
@@ -1236,11 +1291,16 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
       next = end - next < taken ? end : next + taken;
     }
     if (cur == kDone && lf == kNoLeaf && entry != RT_MISS) {   // enter mesh m
-      const DevObject ob = sc.objects[sc.mesh_objects[m]];
+      const DevObject& ob = sc.objects[sc.mesh_objects[m]];
       br = make_box_ray(o, dn, ob);
       root = ob.root; first_tri = ob.first;
       mh.t = INFINITY; mh.t_raw = 0.0; mh.index = RT_MISS; mh.slot = 0;
       cur = 0; sp = 0;
+      if (!model_gate_certain(ob, br)) {
+        // the reference's own box test of the model, on the ray as it was built (the direction before re-normalisation)
+        const double2 oz_dx = q.oz_dx()[entry], d_yz = q.d_yz()[entry];
+        if (!model_gate_exact(ob.gate_lo, ob.gate_hi, o, mk(oz_dx.y, d_yz.x, d_yz.y))) cur = kDone;
+      }
     }
     if (__ballot(entry != RT_MISS) == 0) break;
     const bool refillable = next < end;
@@ -1409,6 +1469,19 @@ __global__ void sum_counts_kernel(const uint32_t* counts, uint32_t n_levels, uns
   if (threadIdx.x == 0) *total += s;
 }
 
+// One wave: lane r looks at region r of every level.
+__global__ void check_overflow_kernel(const uint32_t* counts, uint32_t n_levels, uint32_t pair_level0, uint32_t n_pairs,
+                                      uint32_t region_entries, uint32_t* flag) {
+  bool bad = false;
+  for (uint32_t level = 0; level < n_levels; ++level) bad = bad || counts[(level * kShards + threadIdx.x) * kCountStride + kOverflowWord] != 0u;
+  for (uint32_t k = 0; k < n_pairs; ++k) {
+    const unsigned long long both = (unsigned long long)counts[(k * kShards + threadIdx.x) * kCountStride] +
+                                    counts[((pair_level0 + k) * kShards + threadIdx.x) * kCountStride];
+    bad = bad || both > region_entries;
+  }
+  if (bad) *flag = 1u;
+}
+
 // mean, XYZ -> RGB, clamp, gamma 1/2.2, `(256 * v) as u8` (src/integrators/integrator.rs:79-90,
 // src/spectrum/mod.rs:630-636). A Rust float->u8 cast saturates and maps NaN to 0.
 __global__ void __launch_bounds__(kBlock) tonemap_kernel(const float* __restrict__ xyz_sum, float spp, uint32_t n_pixels,
@@ -1557,6 +1630,11 @@ void launch_resolve(const BatchDesc& b, TraceOutputs o, float* xyz_sum, hipStrea
 void launch_sum_counts(const uint32_t* counts, uint32_t n_levels, unsigned long long* total, hipStream_t s) {
   static_assert(kShards == 64, "sum_counts_kernel reduces one wave of kShards lanes");
   hipLaunchKernelGGL(sum_counts_kernel, dim3(1), 64, 0, s, counts, n_levels, total);
+}
+
+void launch_check_overflow(const uint32_t* counts, uint32_t n_levels, uint32_t pair_level0, uint32_t n_pairs,
+                           uint32_t region_entries, uint32_t* flag, hipStream_t s) {
+  hipLaunchKernelGGL(check_overflow_kernel, dim3(1), 64, 0, s, counts, n_levels, pair_level0, n_pairs, region_entries, flag);
 }
 
 void launch_tonemap(const float* xyz_sum, uint32_t spp, uint32_t n_pixels, uint8_t* rgb8, hipStream_t s) {

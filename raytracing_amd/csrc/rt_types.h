@@ -38,9 +38,17 @@ struct DevObject {
   double radius;       // the whole object lies within this distance of center
   float box_lo[3];     // binary32 box around the whole object, relative to center, padded and rounded outward
   float box_hi[3];
-  uint32_t pad2[2];
+  // Models only: the box ModelObj::intersect tests before it looks at any triangle (src/shapes/model_obj.rs:62-66,78):
+  // the union of the triangles' boxes grown from AABB::empty(), which is the origin point (src/geometry/aabb.rs:15-20).
+  // gate_lo/gate_hi is the exact binary64 box; inner_lo/inner_hi is a binary32 box relative to center that lies strictly
+  // inside it (shrunk and rounded inward): a ray that crosses the inner box certainly passes the exact test, so only the
+  // rays in the thin shell between the two run the binary64 slab test.
+  float inner_lo[3];
+  float inner_hi[3];
+  double gate_lo[3];
+  double gate_hi[3];
 };
-static_assert(sizeof(DevObject) == 96, "DevObject must be 96 bytes");
+static_assert(sizeof(DevObject) == 160, "DevObject must be 160 bytes");
 
 struct DevSphere {
   double l2w[12];

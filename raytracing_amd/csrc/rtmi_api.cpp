@@ -62,7 +62,7 @@ struct DevBuf {
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
-struct DeviceStats { unsigned long long bounce_segments; TraversalCounters trav; unsigned long long mesh_rays; };
+struct DeviceStats { unsigned long long bounce_segments; TraversalCounters trav; unsigned long long mesh_rays; uint32_t overflow, pad; };
 
 }  // namespace
 
@@ -72,7 +72,7 @@ struct rtmi_ctx {
   // workspace shared by every scene of the context (one call at a time per context)
   DevBuf queue_mem[2];
   PathQueue queue[2];
-  size_t queue_paths = 0;
+  size_t queue_entries = 0;       // entries of each path queue (kShards regions of queue_entries / kShards)
   bool queue_deep = false;
   DevBuf contrib, counts, tiles, stats, rays, hits, spectra_out, image;
   DevBuf emit_mem, mesh_list;
@@ -81,9 +81,11 @@ struct rtmi_ctx {
   size_t emit_paths = 0;
   bool emit_deep = false;
   bool batch_is_default = true;   // max_batch_paths was not chosen by the caller: it may shrink if memory is short
+  bool inline_emit = false;       // RTMI_INLINE_EMIT (read once, when the context is created): no emit queue, for A/B measurements
   void release_workspace() {
     for (DevBuf* b : {&queue_mem[0], &queue_mem[1], &contrib, &emit_mem, &mesh_list}) b->release();
-    queue_paths = 0; queue_deep = false; emit_paths = 0; emit_deep = false;
+    queue_entries = 0; queue_deep = false; emit_paths = 0; emit_deep = false;
+    queue[0] = queue[1] = PathQueue{}; emit = EmitQueue{}; emit_region_entries = 0;
   }
 };
 
@@ -122,18 +124,22 @@ constexpr size_t kCountLevelWords = size_t(kShards) * kCountStride;            /
 constexpr size_t kCountLevels = 2 * RT_MAX_DEPTH + 5;
 constexpr size_t kCountBytes = kCountLevels * kCountLevelWords * sizeof(uint32_t);
 
-int ensure_workspace(rtmi_ctx* ctx, size_t paths, bool deep, bool want_queues) {
-  if (want_queues && (paths > ctx->queue_paths || (deep && !ctx->queue_deep))) {
-    const size_t p = std::max(paths, ctx->queue_paths);
+// slack_chunks: see region_chunks(). A failed allocation leaves the context as release_workspace() would: nothing
+// that a later call could mistake for a usable buffer.
+int ensure_workspace(rtmi_ctx* ctx, size_t paths, size_t slack_chunks, bool deep, bool want_queues) {
+  const size_t entries = queue_entries(paths, slack_chunks);
+  if (want_queues && (entries > ctx->queue_entries || (deep && !ctx->queue_deep))) {
+    const size_t e = std::max(entries, ctx->queue_entries);
     const bool d = deep || ctx->queue_deep;
+    ctx->queue_entries = 0; ctx->queue_deep = false;
+    ctx->queue[0] = ctx->queue[1] = PathQueue{};
+    for (DevBuf* b : {&ctx->queue_mem[0], &ctx->queue_mem[1], &ctx->mesh_list}) b->release();
     for (int i = 0; i < 2; ++i) {
-      ctx->queue_mem[i].release();
-      if (int rc = ctx->queue_mem[i].reserve(queue_bytes(queue_entries(p), d))) return rc;
-      ctx->queue[i] = carve_queue(ctx->queue_mem[i].p, queue_entries(p), d);
+      if (int rc = ctx->queue_mem[i].reserve(queue_bytes(e, d))) return rc;
+      ctx->queue[i] = carve_queue(ctx->queue_mem[i].p, e, d);
     }
-    ctx->mesh_list.release();
-    if (int rc = ctx->mesh_list.reserve(queue_entries(p) * sizeof(uint32_t))) return rc;
-    ctx->queue_paths = p; ctx->queue_deep = d;
+    if (int rc = ctx->mesh_list.reserve(e * sizeof(uint32_t))) return rc;
+    ctx->queue_entries = e; ctx->queue_deep = d;
   }
   if (want_queues && (paths > ctx->emit_paths || (deep && !ctx->emit_deep))) {
     // emit queue: kShards regions, each twice its fair share of the batch (a wave that finds its region full
@@ -141,13 +147,14 @@ int ensure_workspace(rtmi_ctx* ctx, size_t paths, bool deep, bool want_queues) {
     const size_t p = std::max(paths, ctx->emit_paths);
     const bool d = deep || ctx->emit_deep;
     const uint32_t region = uint32_t(((2 * p / kShards + kBlock) + kBlock - 1) / kBlock * kBlock);
-    const size_t entries = size_t(region) * kShards;
+    const size_t entries_e = size_t(region) * kShards;
+    ctx->emit_paths = 0; ctx->emit_deep = false; ctx->emit = EmitQueue{}; ctx->emit_region_entries = 0;
     ctx->emit_mem.release();
-    if (int rc = ctx->emit_mem.reserve(entries * (4 + 4 + 16 + (d ? 16 : 0)) + 4 * 256)) return rc;
+    if (int rc = ctx->emit_mem.reserve(entries_e * (4 + 4 + 16 + (d ? 16 : 0)) + 4 * 256)) return rc;
     char* base = ctx->emit_mem.as<char>();
     auto take = [&](size_t bytes) { void* r = base; base += (bytes + 255) & ~size_t(255); return r; };
-    ctx->emit.slot = (uint32_t*)take(entries * 4); ctx->emit.info = (uint32_t*)take(entries * 4);
-    ctx->emit.chain0 = (uint4*)take(entries * 16); ctx->emit.chain1 = d ? (uint4*)take(entries * 16) : nullptr;
+    ctx->emit.slot = (uint32_t*)take(entries_e * 4); ctx->emit.info = (uint32_t*)take(entries_e * 4);
+    ctx->emit.chain0 = (uint4*)take(entries_e * 16); ctx->emit.chain1 = d ? (uint4*)take(entries_e * 16) : nullptr;
     ctx->emit_region_entries = region; ctx->emit_paths = p; ctx->emit_deep = d;
   }
   if (int rc = ctx->contrib.reserve(paths * 3 * sizeof(float))) return rc;
@@ -191,6 +198,30 @@ void set_object_box(DevObject& ob, const double* lo, const double* hi) {
     if (double(l) > dl) l = std::nextafterf(l, -FLT_MAX);
     if (double(h) < dh) h = std::nextafterf(h, FLT_MAX);
     ob.box_lo[k] = l; ob.box_hi[k] = h;
+  }
+}
+
+// The box ModelObj::new grows for its triangles (src/shapes/model_obj.rs:62-66): AABB::empty() is the origin point
+// (src/geometry/aabb.rs:15-20), then the union with every triangle's box. Stored exactly (binary64), plus a binary32
+// box relative to the object's centre that lies strictly inside it: shrunk by 2^-19 of the farthest corner's distance
+// and of the mesh radius, then rounded inward.
+void set_model_gate(DevObject& ob, const double* verts, uint32_t n_tris, double radius) {
+  double lo[3] = {0.0, 0.0, 0.0}, hi[3] = {0.0, 0.0, 0.0};
+  for (size_t i = 0; i < size_t(n_tris) * 3; ++i)
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = std::fmin(lo[k], verts[i * 3 + k]);
+      hi[k] = std::fmax(hi[k], verts[i * 3 + k]);
+    }
+  double reach = radius;
+  for (int k = 0; k < 3; ++k) reach = std::max(reach, std::max(std::fabs(lo[k] - ob.center[k]), std::fabs(hi[k] - ob.center[k])));
+  const double shrink = reach * 0x1.0p-19 + 1e-30;
+  for (int k = 0; k < 3; ++k) {
+    ob.gate_lo[k] = lo[k]; ob.gate_hi[k] = hi[k];
+    const double dl = (lo[k] - ob.center[k]) + shrink, dh = (hi[k] - ob.center[k]) - shrink;
+    float l = float(dl), h = float(dh);
+    if (double(l) < dl) l = std::nextafterf(l, FLT_MAX);
+    if (double(h) > dh) h = std::nextafterf(h, -FLT_MAX);
+    ob.inner_lo[k] = l; ob.inner_hi[k] = h;
   }
 }
 
@@ -280,11 +311,11 @@ int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra
   const size_t levels_used = split ? mesh_level0 + std::max<uint32_t>(depth, 1) + 1 : mesh_level0;
   HIP_TRY(hipMemsetAsync(counts, 0, levels_used * kCountLevelWords * sizeof(uint32_t), stream));
   const bool deep = depth > 16;
-  if (depth >= 1 && ctx->emit_paths >= n_paths && (!deep || ctx->emit_deep) && !getenv("RTMI_INLINE_EMIT")) {
+  if (depth >= 1 && ctx->emit_paths >= n_paths && (!deep || ctx->emit_deep) && !ctx->inline_emit) {
     o.emit = ctx->emit; o.emit_counts = counts + emit_level * kCountLevelWords; o.emit_region_entries = ctx->emit_region_entries;
   }
   HIP_TRY(hipMemsetAsync(contrib, 0, n_paths * 3 * sizeof(float), stream));
-  const uint32_t region_entries = region_chunks(ctx->queue_paths) * kBlock;
+  const uint32_t region_entries = uint32_t(ctx->queue_entries / kShards);
   auto level_counts = [&](size_t k) { return counts + k * kCountLevelWords; };
   if (!split) {
     clock.begin();
@@ -328,6 +359,8 @@ int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra
     // bounce segments of the two-kernel pipeline: the mesh class of levels 1.. (the other class was summed above)
     if (depth > 1) launch_sum_counts(level_counts(mesh_level0 + 1), depth - 1, &ds->bounce_segments, stream);
   }
+  if (ctx->queue_entries) launch_check_overflow(counts, uint32_t(levels_used), uint32_t(mesh_level0), split ? std::max<uint32_t>(depth, 1) + 1 : 0,
+                                                region_entries, &ds->overflow, stream);
   HIP_TRY(hipGetLastError());
   return RTMI_OK;
 }
@@ -360,8 +393,8 @@ extern "C" int rtmi_ctx_create(int device_id, uint64_t max_batch_paths, rtmi_ctx
   ctx->batch_is_default = max_batch_paths == 0;
   if (ctx->max_batch_paths < 256) ctx->max_batch_paths = 256;
   if (ctx->max_batch_paths > (1ull << 30)) ctx->max_batch_paths = 1ull << 30;
-  upload_constants(spectrum_tables());
-  HIP_TRY(hipGetLastError());
+  ctx->inline_emit = getenv("RTMI_INLINE_EMIT") != nullptr;
+  HIP_TRY(upload_constants(spectrum_tables()));
   *out = ctx.release();
   return RTMI_OK;
 }
@@ -539,6 +572,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
         dobj.box_lo[k] = std::min(r.lo0[k], r.lo1[k]);
         dobj.box_hi[k] = std::max(r.hi0[k], r.hi1[k]);
       }
+      set_model_gate(dobj, o.count ? d->triangles[o.first].v : nullptr, o.count, bb.radius);
       mesh_objects.push_back(i);
       nodes.insert(nodes.end(), bb.nodes.begin(), bb.nodes.end());
       mesh_tris.insert(mesh_tris.end(), bb.tris.begin(), bb.tris.end());
@@ -619,7 +653,7 @@ extern "C" int rtmi_intersect_batch(rtmi_scene* s, const rtmi_ray* rays, size_t 
   const size_t chunk = std::min<size_t>(std::max<size_t>(n, 1), size_t(1) << 24);
   if (int rc = ctx->rays.reserve(chunk * sizeof(rtmi_ray))) return rc;
   if (int rc = ctx->hits.reserve(chunk * sizeof(rtmi_hit))) return rc;
-  if (int rc = ensure_workspace(ctx, 1, false, false)) return rc;
+  if (int rc = ensure_workspace(ctx, 1, 0, false, false)) return rc;
   DeviceStats* ds = ctx->stats.as<DeviceStats>();
   const bool count = stats != nullptr;
   if (count) HIP_TRY(hipMemset(ds, 0, sizeof *ds));
@@ -658,7 +692,7 @@ extern "C" int rtmi_trace_batch(rtmi_scene* s, const rtmi_ray* rays, size_t n, u
   Timer timer;
   const size_t chunk = std::min<size_t>(std::max<size_t>(n, 1), std::min<uint64_t>(ctx->max_batch_paths, 1u << 22));
   const bool deep = max_depth > 16;
-  if (int rc = ensure_workspace(ctx, chunk, deep, true)) return rc;
+  if (int rc = ensure_workspace(ctx, chunk, 0, deep, true)) return rc;
   if (int rc = ctx->rays.reserve(chunk * sizeof(rtmi_ray))) return rc;
   if (int rc = ctx->spectra_out.reserve(chunk * RT_NBINS * sizeof(float))) return rc;
   DeviceStats* ds = ctx->stats.as<DeviceStats>();
@@ -734,7 +768,7 @@ extern "C" int rtmi_render_accumulate(rtmi_scene* s, const rtmi_camera* cam, con
     tiles_per_batch = uint32_t(std::min<uint64_t>(tiles.size(), cap / per_tile));
     samples_per_batch = uint32_t(std::min<uint64_t>(n_samples, std::max<uint64_t>(1, cap / (tiles_per_batch * per_tile))));
     batch_paths = size_t(tiles_per_batch) * per_tile * samples_per_batch;
-    const int rc = ensure_workspace(ctx, batch_paths, deep, two_kernel || (p->integrator == RTMI_INT_RANDOM_WALK && p->max_depth > 1));
+    const int rc = ensure_workspace(ctx, batch_paths, samples_per_batch, deep, two_kernel || (p->integrator == RTMI_INT_RANDOM_WALK && p->max_depth > 1));
     if (rc == RTMI_OK) break;
     // The default batch is sized for an otherwise empty 288 GB device. If the workspace does not fit, halve the
     // batch (the image does not depend on it) rather than fail; a caller-chosen cap is never second-guessed.
@@ -791,6 +825,9 @@ extern "C" int rtmi_render_collect_stats(rtmi_scene* s, void* stream_, rtmi_stat
   if (s->ctx->stats.p) {
     DeviceStats h;
     HIP_TRY(hipMemcpy(&h, s->ctx->stats.p, sizeof h, hipMemcpyDeviceToHost));
+    if (h.overflow)
+      return fail(RTMI_INTERNAL, "a path-queue region overflowed and paths were dropped: the image of this render is incomplete "
+                                 "(internal sizing error; please report the scene and the batch size)");
     stats->segments += h.bounce_segments;
     stats->nodes_visited = h.trav.nodes; stats->prims_tested = h.trav.prims; stats->mesh_rays = h.mesh_rays;
     if (getenv("RTMI_VERBOSE") && h.trav.node_slots)

@@ -262,6 +262,91 @@ def test_degenerate_meshes_through_the_two_kernel_pipeline(ctx):
             assert (gpu8 == ref8).mean() >= 0.995, build.__name__
 
 
+def test_model_box_gate_on_faces_and_edges(ctx):
+    """ModelObj::intersect first tests the ray against the model's own box (grown from the origin point,
+    src/shapes/model_obj.rs:62-66,78) with exact binary64 slabs (src/geometry/aabb.rs:136-247); a ray that fails it
+    reports no hit even where Moller-Trumbore accepts a triangle lying in the box's surface. Rays in the faces and
+    along the edges of axis-aligned cubes, from origins on, just inside and just outside the box planes, must come out
+    as the oracle's linear scan behind the same gate reports them -- every one of them, not 99.99 %."""
+    from raytracing_amd import api
+    from raytracing_amd.scene_builder import SceneBuilder, load_golden_mesh
+
+    def build(from_rgb):
+        b = SceneBuilder(from_rgb)
+        b.add_model(load_golden_mesh("cubo") * 0.5 + np.tile(np.array([1.5, 0.25, 0.75]), 3), b.material("Lambertian", (0.5, 0.5, 0.5)))
+        b.add_model(load_golden_mesh("cubo"), b.material("Lambertian", (0.6, 0.6, 0.6)))   # +-3: contains the origin
+        return b
+
+    dirs = [d for d in np.array(np.meshgrid([-1, 0, 1], [-1, 0, 1], [-1, 0, 1])).T.reshape(-1, 3) if d.any()]
+    dirs += [(1.0, 1e-17, 0.0), (0.0, 1.0, 1e-300), (1e-9, 1.0, -1e-9), (0.3, -0.7, 0.2)]
+    dirs = np.array(dirs, dtype=np.float64)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    rays = []
+    for lo, hi in (((0.0, -1.25, -0.75), (3.0, 1.75, 2.25)), ((-3.0, -3.0, -3.0), (3.0, 3.0, 3.0)), ((0.0, 0.0, 0.0), (3.0, 1.75, 2.25))):
+        per_axis = []
+        for k in range(3):
+            l, h = lo[k], hi[k]
+            per_axis.append([np.nextafter(l, -np.inf), l, np.nextafter(l, np.inf), 0.5 * (l + h), np.nextafter(h, -np.inf), h,
+                             np.nextafter(h, np.inf), l - 2.0, h + 2.0])
+        for x in per_axis[0]:
+            for y in per_axis[1]:
+                for z in per_axis[2]:
+                    for d in dirs:
+                        rays.append(((x, y, z), d))
+    arr = np.zeros(len(rays), dtype=O.RAY_DT)
+    arr["o"] = [r[0] for r in rays]
+    arr["d"] = [r[1] for r in rays]
+    for rule in (O.HIT_FIRST_INDEX, O.HIT_NEAREST):
+        osc = O.Scene(*build(O.from_rgb).arrays(), hit_rule=rule)
+        gsc = api.Scene(ctx, *build(None).arrays(), hit_rule=rule)
+        gpu, ref = gsc.intersect_batch(arr), osc.intersect_batch(arr)
+        same = (gpu["obj"] == ref["obj"]) & (gpu["prim"] == ref["prim"])
+        assert same.all(), "rule %d: %d of %d edge rays differ, first at %d" % (rule, (~same).sum(), len(arr), int(np.argmax(~same)))
+        hit = ref["obj"] != O.MISS
+        assert hit.any() and (~hit).any()
+        assert (gpu["t"][hit].view(np.uint64) == ref["t"][hit].view(np.uint64)).all()
+        # the same rays as level-0 rays of the two-kernel pipeline (traverse_kernel applies the gate there)
+        spectra_g, _ = gsc.trace_batch(arr, O.INT_ALBEDO, 0, seed=0)
+        spectra_r, _ = osc.trace_batch(arr, O.INT_ALBEDO, 0, seed=0)
+        assert (spectra_g.view(np.uint32) == spectra_r.view(np.uint32)).all()
+
+
+def test_sealed_scene_fills_every_queue_region(ctx):
+    """Inside a closed Lambertian box whose faces look inward every path survives every bounce, so each queue level holds
+    the whole batch and every region of the queues receives as many paths as it can. Batch sizes that are multiples
+    of 256 * 64 (and some that are not) must neither drop a path nor change a bit of the image."""
+    from raytracing_amd import api
+    from raytracing_amd.scene_builder import SceneBuilder, load_golden_mesh
+
+    def build(from_rgb):
+        b = SceneBuilder(from_rgb)
+        inward = load_golden_mesh("cubo").reshape(-1, 3, 3)[:, ::-1, :].reshape(-1, 9)    # reversed winding
+        b.add_model(inward, b.material("Lambertian", (0.9, 0.9, 0.9)))
+        lamp = load_golden_mesh("cubo") * 0.01 + np.tile(np.array([0.0, 0.0, 2.5]), 3)
+        b.add_model(lamp, b.material("Emitter", (1.0, 1.0, 1.0)))
+        return b
+
+    cam_args = ((0.5, 0.25, 0.0), 0.1, 110.0, (0.0, 0.1, 0.3), 192, 128)
+    osc, ocam = O.Scene(*build(O.from_rgb).arrays()), O.camera(*cam_args)
+    gcam = api.camera_new(*cam_args)
+    p = api.render_params(O.INT_RANDOM_WALK, 12, 6, seed=21)
+    ref8, _, ref_lin, ref_st = osc.render(ocam, O.INT_RANDOM_WALK, 12, 6, seed=21)
+    assert ref_st.segments >= 0.98 * 12 * ref_st.paths       # nearly every path runs to the depth limit
+    images = []
+    for batch in (0, 16384, 3 * 16384, 8192, 1 << 18):
+        c = ctx if batch == 0 else api.Context(0, max_batch_paths=batch)
+        gsc = api.Scene(c, *build(None).arrays())
+        img, xyz, st = gsc.render(gcam, p)                    # raises if a queue region overflowed
+        assert st["segments"] == ref_st.segments and st["paths"] == ref_st.paths, batch
+        images.append(xyz)
+        gsc.close()
+        if batch:
+            c.close()
+    for xyz in images[1:]:
+        assert (xyz.view(np.uint32) == images[0].view(np.uint32)).all()
+    assert (images[0] == ref_lin).all(axis=2).mean() >= 0.999
+
+
 def test_small_batches_equal_large(ctx):
     """The batch size only changes scheduling, never the image."""
     from raytracing_amd import api
