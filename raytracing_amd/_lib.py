@@ -18,7 +18,7 @@ LIB_PATH = Path(os.environ["RTMI_LIB"]).resolve() if os.environ.get("RTMI_LIB") 
 NBINS = 60
 MISS = 0xFFFFFFFF
 MAX_DEPTH = 32
-OK, BAD_ARG, NO_DEVICE, OOM, HIP_ERROR, UNSUPPORTED = 0, -1, -2, -3, -4, -5
+OK, BAD_ARG, NO_DEVICE, OOM, HIP_ERROR, UNSUPPORTED, RCCL_ERROR, INTERNAL = 0, -1, -2, -3, -4, -5, -6, -7
 OBJ_SPHERE, OBJ_TRIANGLE, OBJ_MODEL = 0, 1, 2
 MAT_EMITTER, MAT_LAMBERTIAN, MAT_SPECULAR, MAT_GLOSSY, MAT_DIELECTRIC = 0, 1, 2, 3, 4
 HAS_AMBIENT, HAS_EMITTED, HAS_DIFFUSED, HAS_SPECULAR = 1, 2, 4, 8

@@ -170,6 +170,8 @@ void launch_traverse(const DevScene& sc, PathQueue q, MeshList mesh, uint32_t ma
 void launch_emit(const DevScene& sc, TraceOutputs o, bool deep, uint32_t max_entries, hipStream_t s);
 // rays: n x {o[3], d[3]} doubles; hits: n x rtmi_hit (64 bytes); both device memory.
 void launch_intersect(const DevScene& sc, const void* rays, size_t n, void* hits, TraversalCounters* counters, hipStream_t s);
+// tiles[j] = first + j * stride for j < n: the tile ids (x-major) of one render's share
+void launch_fill_tiles(uint32_t* tiles, uint32_t n, uint32_t first, uint32_t stride, hipStream_t s);
 // Adds the batch's per-slot contributions into the per-pixel sums, in sample order.
 void launch_resolve(const BatchDesc& b, TraceOutputs o, float* xyz_sum, hipStream_t s);
 // *total += every fill counter of n_levels consecutive queue levels

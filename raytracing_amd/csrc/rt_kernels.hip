@@ -1469,6 +1469,11 @@ __global__ void sum_counts_kernel(const uint32_t* counts, uint32_t n_levels, uns
   if (threadIdx.x == 0) *total += s;
 }
 
+__global__ void __launch_bounds__(kBlock) fill_tiles_kernel(uint32_t* __restrict__ tiles, uint32_t n, uint32_t first, uint32_t stride) {
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  if (j < n) tiles[j] = first + j * stride;
+}
+
 // One wave: lane r looks at region r of every level.
 __global__ void check_overflow_kernel(const uint32_t* counts, uint32_t n_levels, uint32_t pair_level0, uint32_t n_pairs,
                                       uint32_t region_entries, uint32_t* flag) {
@@ -1630,6 +1635,11 @@ void launch_resolve(const BatchDesc& b, TraceOutputs o, float* xyz_sum, hipStrea
 void launch_sum_counts(const uint32_t* counts, uint32_t n_levels, unsigned long long* total, hipStream_t s) {
   static_assert(kShards == 64, "sum_counts_kernel reduces one wave of kShards lanes");
   hipLaunchKernelGGL(sum_counts_kernel, dim3(1), 64, 0, s, counts, n_levels, total);
+}
+
+void launch_fill_tiles(uint32_t* tiles, uint32_t n, uint32_t first, uint32_t stride, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(fill_tiles_kernel, dim3((n + kBlock - 1) / kBlock), kBlock, 0, s, tiles, n, first, stride);
 }
 
 void launch_check_overflow(const uint32_t* counts, uint32_t n_levels, uint32_t pair_level0, uint32_t n_pairs,

@@ -66,26 +66,38 @@ struct DeviceStats { unsigned long long bounce_segments; TraversalCounters trav;
 
 }  // namespace
 
-struct rtmi_ctx {
-  int device = 0;
-  uint64_t max_batch_paths = 0;
-  // workspace shared by every scene of the context (one call at a time per context)
-  DevBuf queue_mem[2];
-  PathQueue queue[2];
+// Device memory one batch of launches works in, beyond the caller's inputs and outputs. A context owns one that grows
+// on demand (ensure_workspace).
+struct Workspace {
+  PathQueue queue[2]{};
   size_t queue_entries = 0;       // entries of each path queue (kShards regions of queue_entries / kShards)
   bool queue_deep = false;
-  DevBuf contrib, counts, tiles, stats, rays, hits, spectra_out, image;
-  DevBuf emit_mem, mesh_list;
+  uint32_t* mesh_list = nullptr;  // queue_entries positions
   EmitQueue emit{};
   uint32_t emit_region_entries = 0;
   size_t emit_paths = 0;
   bool emit_deep = false;
+  float* contrib = nullptr;       // 3 floats per path slot
+  uint32_t* counts = nullptr;     // kCountBytes
+  DeviceStats* stats = nullptr;
+  uint32_t* tiles = nullptr;      // tile ids of the current render
+};
+
+struct rtmi_ctx {
+  int device = 0;
+  uint64_t max_batch_paths = 0;
+  // workspace shared by every scene of the context (one call at a time per context)
+  Workspace ws;
+  DevBuf queue_mem[2];
+  DevBuf contrib, counts, tiles, stats, rays, hits, spectra_out, image;
+  DevBuf emit_mem, mesh_list;
   bool batch_is_default = true;   // max_batch_paths was not chosen by the caller: it may shrink if memory is short
   bool inline_emit = false;       // RTMI_INLINE_EMIT (read once, when the context is created): no emit queue, for A/B measurements
   void release_workspace() {
     for (DevBuf* b : {&queue_mem[0], &queue_mem[1], &contrib, &emit_mem, &mesh_list}) b->release();
-    queue_entries = 0; queue_deep = false; emit_paths = 0; emit_deep = false;
-    queue[0] = queue[1] = PathQueue{}; emit = EmitQueue{}; emit_region_entries = 0;
+    ws.queue_entries = 0; ws.queue_deep = false; ws.emit_paths = 0; ws.emit_deep = false;
+    ws.queue[0] = ws.queue[1] = PathQueue{}; ws.emit = EmitQueue{}; ws.emit_region_entries = 0;
+    ws.mesh_list = nullptr; ws.contrib = nullptr;
   }
 };
 
@@ -97,6 +109,7 @@ struct rtmi_scene {
   // bookkeeping of the last render_accumulate, completed by rtmi_render_collect_stats
   rtmi_stats pending{};
   bool counting = false;
+  DeviceStats* last_stats = nullptr;   // device counters of the last render_accumulate (the context's or the static scratch's)
   bool fused_only = false;   // RTMI_PIPELINE=fused: one kernel per bounce even with meshes (for A/B measurements)
 };
 
@@ -124,45 +137,62 @@ constexpr size_t kCountLevelWords = size_t(kShards) * kCountStride;            /
 constexpr size_t kCountLevels = 2 * RT_MAX_DEPTH + 5;
 constexpr size_t kCountBytes = kCountLevels * kCountLevelWords * sizeof(uint32_t);
 
+size_t emit_entries_for(size_t paths) {
+  // emit queue: kShards regions, each twice its fair share of the batch (a wave that finds its region full
+  // evaluates in place, so this is a performance knob, not a correctness bound)
+  return size_t(((2 * paths / kShards + kBlock) + kBlock - 1) / kBlock * kBlock);
+}
+size_t emit_bytes(size_t region_entries, bool deep) { return region_entries * kShards * (4 + 4 + 16 + (deep ? 16 : 0)) + 4 * 256; }
+
+EmitQueue carve_emit(void* mem, size_t region_entries, bool deep) {
+  const size_t entries = region_entries * kShards;
+  char* base = static_cast<char*>(mem);
+  auto take = [&](size_t bytes) { void* r = base; base += (bytes + 255) & ~size_t(255); return r; };
+  EmitQueue e;
+  e.slot = (uint32_t*)take(entries * 4); e.info = (uint32_t*)take(entries * 4);
+  e.chain0 = (uint4*)take(entries * 16); e.chain1 = deep ? (uint4*)take(entries * 16) : nullptr;
+  return e;
+}
+
 // slack_chunks: see region_chunks(). A failed allocation leaves the context as release_workspace() would: nothing
 // that a later call could mistake for a usable buffer.
 int ensure_workspace(rtmi_ctx* ctx, size_t paths, size_t slack_chunks, bool deep, bool want_queues) {
+  Workspace& ws = ctx->ws;
   const size_t entries = queue_entries(paths, slack_chunks);
-  if (want_queues && (entries > ctx->queue_entries || (deep && !ctx->queue_deep))) {
-    const size_t e = std::max(entries, ctx->queue_entries);
-    const bool d = deep || ctx->queue_deep;
-    ctx->queue_entries = 0; ctx->queue_deep = false;
-    ctx->queue[0] = ctx->queue[1] = PathQueue{};
+  if (want_queues && (entries > ws.queue_entries || (deep && !ws.queue_deep))) {
+    const size_t e = std::max(entries, ws.queue_entries);
+    const bool d = deep || ws.queue_deep;
+    ws.queue_entries = 0; ws.queue_deep = false; ws.mesh_list = nullptr;
+    ws.queue[0] = ws.queue[1] = PathQueue{};
     for (DevBuf* b : {&ctx->queue_mem[0], &ctx->queue_mem[1], &ctx->mesh_list}) b->release();
     for (int i = 0; i < 2; ++i) {
       if (int rc = ctx->queue_mem[i].reserve(queue_bytes(e, d))) return rc;
-      ctx->queue[i] = carve_queue(ctx->queue_mem[i].p, e, d);
+      ws.queue[i] = carve_queue(ctx->queue_mem[i].p, e, d);
     }
     if (int rc = ctx->mesh_list.reserve(e * sizeof(uint32_t))) return rc;
-    ctx->queue_entries = e; ctx->queue_deep = d;
+    ws.mesh_list = ctx->mesh_list.as<uint32_t>();
+    ws.queue_entries = e; ws.queue_deep = d;
   }
-  if (want_queues && (paths > ctx->emit_paths || (deep && !ctx->emit_deep))) {
-    // emit queue: kShards regions, each twice its fair share of the batch (a wave that finds its region full
-    // evaluates in place, so this is a performance knob, not a correctness bound)
-    const size_t p = std::max(paths, ctx->emit_paths);
-    const bool d = deep || ctx->emit_deep;
-    const uint32_t region = uint32_t(((2 * p / kShards + kBlock) + kBlock - 1) / kBlock * kBlock);
-    const size_t entries_e = size_t(region) * kShards;
-    ctx->emit_paths = 0; ctx->emit_deep = false; ctx->emit = EmitQueue{}; ctx->emit_region_entries = 0;
+  if (want_queues && (paths > ws.emit_paths || (deep && !ws.emit_deep))) {
+    const size_t p = std::max(paths, ws.emit_paths);
+    const bool d = deep || ws.emit_deep;
+    const size_t region = emit_entries_for(p);
+    ws.emit_paths = 0; ws.emit_deep = false; ws.emit = EmitQueue{}; ws.emit_region_entries = 0;
     ctx->emit_mem.release();
-    if (int rc = ctx->emit_mem.reserve(entries_e * (4 + 4 + 16 + (d ? 16 : 0)) + 4 * 256)) return rc;
-    char* base = ctx->emit_mem.as<char>();
-    auto take = [&](size_t bytes) { void* r = base; base += (bytes + 255) & ~size_t(255); return r; };
-    ctx->emit.slot = (uint32_t*)take(entries_e * 4); ctx->emit.info = (uint32_t*)take(entries_e * 4);
-    ctx->emit.chain0 = (uint4*)take(entries_e * 16); ctx->emit.chain1 = d ? (uint4*)take(entries_e * 16) : nullptr;
-    ctx->emit_region_entries = region; ctx->emit_paths = p; ctx->emit_deep = d;
+    if (int rc = ctx->emit_mem.reserve(emit_bytes(region, d))) return rc;
+    ws.emit = carve_emit(ctx->emit_mem.p, region, d);
+    ws.emit_region_entries = uint32_t(region); ws.emit_paths = p; ws.emit_deep = d;
   }
+  ws.contrib = nullptr;
   if (int rc = ctx->contrib.reserve(paths * 3 * sizeof(float))) return rc;
+  ws.contrib = ctx->contrib.as<float>();
   if (int rc = ctx->counts.reserve(kCountBytes)) return rc;
+  ws.counts = ctx->counts.as<uint32_t>();
   if (!ctx->stats.p) {
     if (int rc = ctx->stats.reserve(sizeof(DeviceStats))) return rc;
     HIP_TRY(hipMemset(ctx->stats.p, 0, sizeof(DeviceStats)));
   }
+  ws.stats = ctx->stats.as<DeviceStats>();
   return RTMI_OK;
 }
 
@@ -294,14 +324,13 @@ DevCamera to_dev_camera(const rtmi_camera& c) {
   return d;
 }
 
-// Runs the launches of one batch and leaves per-slot contributions in ctx->contrib.
-int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra_out, hipStream_t stream,
+// Runs the launches of one batch in workspace `ws` and leaves the per-slot contributions in ws.contrib.
+int run_batch(rtmi_scene* sc, const Workspace& ws, const BatchDesc& b, size_t n_paths, float* spectra_out, hipStream_t stream,
               KernelClock& clock, uint32_t& launches) {
-  rtmi_ctx* ctx = sc->ctx;
-  uint32_t* counts = ctx->counts.as<uint32_t>();
-  float* contrib = ctx->contrib.as<float>();
+  uint32_t* counts = ws.counts;
+  float* contrib = ws.contrib;
   TraceOutputs o{contrib, contrib + n_paths, contrib + 2 * n_paths, spectra_out, EmitQueue{}, nullptr, 0};
-  DeviceStats* ds = ctx->stats.as<DeviceStats>();
+  DeviceStats* ds = ws.stats;
   TraversalCounters* counters = sc->counting ? &ds->trav : nullptr;
   const uint32_t depth = b.integrator == RT_INT_RANDOM_WALK ? b.max_depth : 0;
   // queue level k holds the paths that enter bounce k; its kShards fill counters sit at counts + k * kCountLevelWords;
@@ -311,20 +340,20 @@ int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra
   const size_t levels_used = split ? mesh_level0 + std::max<uint32_t>(depth, 1) + 1 : mesh_level0;
   HIP_TRY(hipMemsetAsync(counts, 0, levels_used * kCountLevelWords * sizeof(uint32_t), stream));
   const bool deep = depth > 16;
-  if (depth >= 1 && ctx->emit_paths >= n_paths && (!deep || ctx->emit_deep) && !ctx->inline_emit) {
-    o.emit = ctx->emit; o.emit_counts = counts + emit_level * kCountLevelWords; o.emit_region_entries = ctx->emit_region_entries;
+  if (depth >= 1 && ws.emit_paths >= n_paths && (!deep || ws.emit_deep) && !sc->ctx->inline_emit) {
+    o.emit = ws.emit; o.emit_counts = counts + emit_level * kCountLevelWords; o.emit_region_entries = ws.emit_region_entries;
   }
   HIP_TRY(hipMemsetAsync(contrib, 0, n_paths * 3 * sizeof(float), stream));
-  const uint32_t region_entries = uint32_t(ctx->queue_entries / kShards);
+  const uint32_t region_entries = uint32_t(ws.queue_entries / kShards);
   auto level_counts = [&](size_t k) { return counts + k * kCountLevelWords; };
   if (!split) {
     clock.begin();
-    launch_primary(sc->dev, b, ctx->queue[0], level_counts(1), region_entries, o, counters, stream);
+    launch_primary(sc->dev, b, ws.queue[0], level_counts(1), region_entries, o, counters, stream);
     clock.end();
     ++launches;
     for (uint32_t k = 1; k < depth; ++k) {
       clock.begin();
-      launch_bounce(sc->dev, b, ctx->queue[(k - 1) & 1], level_counts(k), uint32_t(n_paths), ctx->queue[k & 1],
+      launch_bounce(sc->dev, b, ws.queue[(k - 1) & 1], level_counts(k), uint32_t(n_paths), ws.queue[k & 1],
                     level_counts(k + 1), region_entries, o, counters, stream);
       clock.end();
       ++launches;
@@ -333,20 +362,20 @@ int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra
     // level k >= 1 lives in queue[k & 1]; level 0 has no queue (queue[0] only carries the listed primary rays' directions and
     // the hit records, at the paths' own indices). Per level: traverse, then shade (which fills level k + 1).
     // level k's fill counters: mesh class at level_counts(mesh_level0 + k), the rest at level_counts(k)
-    auto mesh_list = [&](size_t k) { return MeshList{k == 0 ? ctx->mesh_list.as<uint32_t>() : nullptr, level_counts(mesh_level0 + k)}; };
+    auto mesh_list = [&](size_t k) { return MeshList{k == 0 ? ws.mesh_list : nullptr, level_counts(mesh_level0 + k)}; };
     auto both = [&](size_t k) { return LevelCounts{level_counts(mesh_level0 + k), level_counts(k)}; };
     clock.begin();
-    launch_generate(sc->dev, b, ctx->queue[0], region_entries, mesh_list(0), stream);
+    launch_generate(sc->dev, b, ws.queue[0], region_entries, mesh_list(0), stream);
     clock.end();
     ++launches;
     const uint32_t levels = std::max<uint32_t>(depth, 1);   // albedo / normal integrators: the primary hit only
     for (uint32_t k = 0; k < levels; ++k) {
       const FixedOrigin origin{b.cam.focus[0], b.cam.focus[1], b.cam.focus[2], k == 0 && !b.rays};
       clock.begin(true);
-      launch_traverse(sc->dev, ctx->queue[k & 1], mesh_list(k), uint32_t(n_paths), region_entries, origin, counters, stream);
+      launch_traverse(sc->dev, ws.queue[k & 1], mesh_list(k), uint32_t(n_paths), region_entries, origin, counters, stream);
       clock.end();
       clock.begin();
-      launch_shade(sc->dev, b, k == 0, ctx->queue[k & 1], both(k), uint32_t(n_paths), ctx->queue[(k + 1) & 1], both(k + 1), region_entries, o,
+      launch_shade(sc->dev, b, k == 0, ws.queue[k & 1], both(k), uint32_t(n_paths), ws.queue[(k + 1) & 1], both(k + 1), region_entries, o,
                    stream);
       clock.end();
       launches += 2;
@@ -359,8 +388,8 @@ int run_batch(rtmi_scene* sc, const BatchDesc& b, size_t n_paths, float* spectra
     // bounce segments of the two-kernel pipeline: the mesh class of levels 1.. (the other class was summed above)
     if (depth > 1) launch_sum_counts(level_counts(mesh_level0 + 1), depth - 1, &ds->bounce_segments, stream);
   }
-  if (ctx->queue_entries) launch_check_overflow(counts, uint32_t(levels_used), uint32_t(mesh_level0), split ? std::max<uint32_t>(depth, 1) + 1 : 0,
-                                                region_entries, &ds->overflow, stream);
+  if (ws.queue_entries) launch_check_overflow(counts, uint32_t(levels_used), uint32_t(mesh_level0), split ? std::max<uint32_t>(depth, 1) + 1 : 0,
+                                              region_entries, &ds->overflow, stream);
   HIP_TRY(hipGetLastError());
   return RTMI_OK;
 }
@@ -654,7 +683,7 @@ extern "C" int rtmi_intersect_batch(rtmi_scene* s, const rtmi_ray* rays, size_t 
   if (int rc = ctx->rays.reserve(chunk * sizeof(rtmi_ray))) return rc;
   if (int rc = ctx->hits.reserve(chunk * sizeof(rtmi_hit))) return rc;
   if (int rc = ensure_workspace(ctx, 1, 0, false, false)) return rc;
-  DeviceStats* ds = ctx->stats.as<DeviceStats>();
+  DeviceStats* ds = ctx->ws.stats;
   const bool count = stats != nullptr;
   if (count) HIP_TRY(hipMemset(ds, 0, sizeof *ds));
   for (size_t at = 0; at < n; at += chunk) {
@@ -695,9 +724,9 @@ extern "C" int rtmi_trace_batch(rtmi_scene* s, const rtmi_ray* rays, size_t n, u
   if (int rc = ensure_workspace(ctx, chunk, 0, deep, true)) return rc;
   if (int rc = ctx->rays.reserve(chunk * sizeof(rtmi_ray))) return rc;
   if (int rc = ctx->spectra_out.reserve(chunk * RT_NBINS * sizeof(float))) return rc;
-  DeviceStats* ds = ctx->stats.as<DeviceStats>();
+  DeviceStats* ds = ctx->ws.stats;
   HIP_TRY(hipMemset(ds, 0, sizeof *ds));
-  s->counting = false;
+  s->counting = false; s->last_stats = ds;
   KernelClock clock;
   uint32_t launches = 0, batches = 0;
   for (size_t at = 0; at < n; at += chunk) {
@@ -707,7 +736,7 @@ extern "C" int rtmi_trace_batch(rtmi_scene* s, const rtmi_ray* rays, size_t n, u
     b.integrator = integrator; b.max_depth = max_depth; b.seed = seed;
     b.sample0 = sample_index; b.n_samples = 1;
     b.rays = ctx->rays.as<double>(); b.n_rays = uint32_t(m); b.pixel_base = pixel_base + uint32_t(at);
-    if (int rc = run_batch(s, b, m, ctx->spectra_out.as<float>(), nullptr, clock, launches)) return rc;
+    if (int rc = run_batch(s, ctx->ws, b, m, ctx->spectra_out.as<float>(), nullptr, clock, launches)) return rc;
     HIP_TRY(hipMemcpy(spectra + at * RT_NBINS, ctx->spectra_out.p, m * RT_NBINS * sizeof(float), hipMemcpyDeviceToHost));
     ++batches;
   }
@@ -723,85 +752,79 @@ extern "C" int rtmi_trace_batch(rtmi_scene* s, const rtmi_ray* rays, size_t n, u
 
 // ================================================================================ render
 
-extern "C" int rtmi_render_accumulate(rtmi_scene* s, const rtmi_camera* cam, const rtmi_render_params* p, float* dev_xyz_sum,
-                                      void* stream_, rtmi_stats* stats) {
-  if (int rc = check_scene(s)) return rc;
+namespace {
+
+// What a render call covers, after its arguments have been checked.
+struct RenderPlan {
+  uint32_t T = 16, tiles_x = 0, tiles_y = 0;
+  uint32_t n_tiles = 0;          // tiles of this call's share: k = tile_rank + j * tile_world, j < n_tiles
+  uint32_t first = 0, stride = 1;
+  uint64_t pixels = 0;           // pixels of those tiles that lie inside the image
+  uint32_t s_begin = 0, s_end = 0;
+  bool deep = false, two_kernel = false, want_queues = false;
+};
+
+int plan_render(rtmi_scene* s, const rtmi_camera* cam, const rtmi_render_params* p, const float* dev_xyz_sum, RenderPlan& r) {
   if (!cam || !p || !dev_xyz_sum) return fail(RTMI_BAD_ARG, "NULL argument");
   if (cam->width == 0 || cam->height == 0) return fail(RTMI_BAD_ARG, "camera resolution %ux%u", cam->width, cam->height);
   if (uint64_t(cam->width) * cam->height >= (1ull << 32)) return fail(RTMI_UNSUPPORTED, "image too large");
   if (p->integrator > RTMI_INT_NORMAL) return fail(RTMI_BAD_ARG, "unknown integrator %u", p->integrator);
   if (p->max_depth > RTMI_MAX_DEPTH) return fail(RTMI_UNSUPPORTED, "max_depth %u > %d", p->max_depth, RTMI_MAX_DEPTH);
   if (p->spp == 0) return fail(RTMI_BAD_ARG, "spp is 0");
-  const uint32_t s_begin = p->sample_end ? p->sample_begin : 0, s_end = p->sample_end ? p->sample_end : p->spp;
-  if (s_begin > s_end || s_end > p->spp) return fail(RTMI_BAD_ARG, "sample range [%u,%u) outside [0,%u)", s_begin, s_end, p->spp);
-  const uint32_t T = p->tile_size ? p->tile_size : 16;
-  if (T % kPixelBlock != 0 || T > 1024) return fail(RTMI_BAD_ARG, "tile_size %u must be a multiple of %u", T, kPixelBlock);
+  r.s_begin = p->sample_end ? p->sample_begin : 0; r.s_end = p->sample_end ? p->sample_end : p->spp;
+  if (r.s_begin > r.s_end || r.s_end > p->spp) return fail(RTMI_BAD_ARG, "sample range [%u,%u) outside [0,%u)", r.s_begin, r.s_end, p->spp);
+  r.T = p->tile_size ? p->tile_size : 16;
+  if (r.T % kPixelBlock != 0 || r.T > 1024) return fail(RTMI_BAD_ARG, "tile_size %u must be a multiple of %u", r.T, kPixelBlock);
   if (p->tile_world && p->tile_rank >= p->tile_world) return fail(RTMI_BAD_ARG, "tile_rank %u >= tile_world %u", p->tile_rank, p->tile_world);
-  rtmi_ctx* ctx = s->ctx;
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
-  Timer timer;
-
-  const uint32_t tiles_x = (cam->width + T - 1) / T, tiles_y = (cam->height + T - 1) / T;
-  std::vector<uint32_t> tiles;
-  uint64_t my_pixels = 0;
-  for (uint32_t k = 0; k < tiles_x * tiles_y; ++k) {
-    if (p->tile_world && k % p->tile_world != p->tile_rank) continue;
-    tiles.push_back(k);
-    const uint32_t x0 = (k / tiles_y) * T, y0 = (k % tiles_y) * T;
-    my_pixels += uint64_t(std::min(T, cam->width - x0)) * std::min(T, cam->height - y0);
+  r.tiles_x = (cam->width + r.T - 1) / r.T; r.tiles_y = (cam->height + r.T - 1) / r.T;
+  const uint32_t all = r.tiles_x * r.tiles_y;
+  r.first = p->tile_world ? p->tile_rank : 0; r.stride = p->tile_world ? p->tile_world : 1;
+  r.n_tiles = r.first < all ? (all - r.first + r.stride - 1) / r.stride : 0;
+  r.pixels = 0;
+  for (uint32_t j = 0; j < r.n_tiles; ++j) {
+    const uint32_t k = r.first + j * r.stride;
+    const uint32_t x0 = (k / r.tiles_y) * r.T, y0 = (k % r.tiles_y) * r.T;
+    r.pixels += uint64_t(std::min(r.T, cam->width - x0)) * std::min(r.T, cam->height - y0);
   }
-  const uint32_t n_samples = s_end - s_begin;
-  s->pending = rtmi_stats{};
-  s->pending.paths = my_pixels * n_samples;
-  s->pending.segments = my_pixels * n_samples;  // primary rays; bounce rays are added from the device counters
-  s->counting = (p->flags & RTMI_FLAG_COUNT_TRAVERSAL) != 0;
-  if (tiles.empty() || n_samples == 0) { if (stats) *stats = s->pending; return RTMI_OK; }
-
-  const uint64_t per_tile = uint64_t(T) * T;
-  const bool deep = p->integrator == RTMI_INT_RANDOM_WALK && p->max_depth > 16;
+  r.deep = p->integrator == RTMI_INT_RANDOM_WALK && p->max_depth > 16;
   // the fused kernel needs queues only when paths can continue; the two-kernel pipeline keeps even primary rays in one
-  const bool two_kernel = s->dev.n_meshes > 0 && !s->fused_only;
-  uint32_t tiles_per_batch = 0, samples_per_batch = 0;
-  size_t batch_paths = 0;
-  for (;;) {
-    const uint64_t cap = std::max<uint64_t>(ctx->max_batch_paths, per_tile);
-    tiles_per_batch = uint32_t(std::min<uint64_t>(tiles.size(), cap / per_tile));
-    samples_per_batch = uint32_t(std::min<uint64_t>(n_samples, std::max<uint64_t>(1, cap / (tiles_per_batch * per_tile))));
-    batch_paths = size_t(tiles_per_batch) * per_tile * samples_per_batch;
-    const int rc = ensure_workspace(ctx, batch_paths, samples_per_batch, deep, two_kernel || (p->integrator == RTMI_INT_RANDOM_WALK && p->max_depth > 1));
-    if (rc == RTMI_OK) break;
-    // The default batch is sized for an otherwise empty 288 GB device. If the workspace does not fit, halve the
-    // batch (the image does not depend on it) rather than fail; a caller-chosen cap is never second-guessed.
-    if (rc != RTMI_OOM || !ctx->batch_is_default || ctx->max_batch_paths <= (1ull << 20)) return rc;
-    (void)hipGetLastError();
-    ctx->release_workspace();
-    ctx->max_batch_paths >>= 1;
-  }
-  if (int rc = ctx->tiles.reserve(tiles.size() * sizeof(uint32_t))) return rc;
-  HIP_TRY(hipMemcpyAsync(ctx->tiles.p, tiles.data(), tiles.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipStreamSynchronize(stream));  // `tiles` is about to go out of scope
-  HIP_TRY(hipMemsetAsync(ctx->stats.p, 0, sizeof(DeviceStats), stream));
+  r.two_kernel = s->dev.n_meshes > 0 && !s->fused_only;
+  r.want_queues = r.two_kernel || (p->integrator == RTMI_INT_RANDOM_WALK && p->max_depth > 1);
+  const uint32_t n_samples = r.s_end - r.s_begin;
+  s->pending = rtmi_stats{};
+  s->pending.paths = r.pixels * n_samples;
+  s->pending.segments = r.pixels * n_samples;  // primary rays; bounce rays are added from the device counters
+  s->counting = (p->flags & RTMI_FLAG_COUNT_TRAVERSAL) != 0;
+  return RTMI_OK;
+}
 
+// The batches of one render in workspace `ws`: runs of tiles x runs of samples, each at most tiles_per_batch x
+// samples_per_batch paths; every batch ends by adding its contributions to the per-pixel sums.
+int render_batches(rtmi_scene* s, const Workspace& ws, const rtmi_camera* cam, const rtmi_render_params* p, const RenderPlan& r,
+                   uint32_t tiles_per_batch, uint32_t samples_per_batch, float* dev_xyz_sum, hipStream_t stream, const Timer& timer) {
+  launch_fill_tiles(ws.tiles, r.n_tiles, r.first, r.stride, stream);
+  HIP_TRY(hipMemsetAsync(ws.stats, 0, sizeof(DeviceStats), stream));
+  s->last_stats = ws.stats;
   KernelClock clock;
   clock.on = (p->flags & RTMI_FLAG_TIME_KERNELS) != 0;
   clock.stream = stream;
   uint32_t launches = 0, batches = 0;
   double kernel_ms = 0.0;
-  for (size_t t0 = 0; t0 < tiles.size(); t0 += tiles_per_batch) {
-    const uint32_t nt = uint32_t(std::min<size_t>(tiles_per_batch, tiles.size() - t0));
-    for (uint32_t s0 = s_begin; s0 < s_end; s0 += samples_per_batch) {
+  const uint64_t per_tile = uint64_t(r.T) * r.T;
+  for (uint32_t t0 = 0; t0 < r.n_tiles; t0 += tiles_per_batch) {
+    const uint32_t nt = std::min(tiles_per_batch, r.n_tiles - t0);
+    for (uint32_t s0 = r.s_begin; s0 < r.s_end; s0 += samples_per_batch) {
       BatchDesc b{};
       b.cam = to_dev_camera(*cam);
-      b.tile_list = ctx->tiles.as<uint32_t>() + t0; b.n_tiles = nt; b.tile_size = T; b.tiles_y = tiles_y;
+      b.tile_list = ws.tiles + t0; b.n_tiles = nt; b.tile_size = r.T; b.tiles_y = r.tiles_y;
       b.n_local_pixels = uint32_t(nt * per_tile);
       b.by_local_pixels = make_fast_div(b.n_local_pixels); b.by_tile_pixels = make_fast_div(uint32_t(per_tile));
-      b.by_tiles_y = make_fast_div(tiles_y); b.by_blocks_per_row = make_fast_div(T / kPixelBlock);
-      b.sample0 = s0; b.n_samples = std::min(samples_per_batch, s_end - s0);
+      b.by_tiles_y = make_fast_div(r.tiles_y); b.by_blocks_per_row = make_fast_div(r.T / kPixelBlock);
+      b.sample0 = s0; b.n_samples = std::min(samples_per_batch, r.s_end - s0);
       b.integrator = p->integrator; b.max_depth = p->max_depth; b.seed = p->seed;
       const size_t n_paths = size_t(b.n_local_pixels) * b.n_samples;
-      if (int rc = run_batch(s, b, n_paths, nullptr, stream, clock, launches)) return rc;
-      float* contrib = ctx->contrib.as<float>();
-      launch_resolve(b, TraceOutputs{contrib, contrib + n_paths, contrib + 2 * n_paths, nullptr, EmitQueue{}, nullptr, 0}, dev_xyz_sum, stream);
+      if (int rc = run_batch(s, ws, b, n_paths, nullptr, stream, clock, launches)) return rc;
+      launch_resolve(b, TraceOutputs{ws.contrib, ws.contrib + n_paths, ws.contrib + 2 * n_paths, nullptr, EmitQueue{}, nullptr, 0}, dev_xyz_sum, stream);
       HIP_TRY(hipGetLastError());
       if (clock.on) kernel_ms += clock.drain();
       ++batches;
@@ -810,8 +833,43 @@ extern "C" int rtmi_render_accumulate(rtmi_scene* s, const rtmi_camera* cam, con
   s->pending.launches = launches; s->pending.batches = batches; s->pending.ms_kernels = kernel_ms;
   s->pending.ms_traverse = clock.traverse_ms; s->pending.traverse_launches = clock.traverse_launches;
   s->pending.ms_total = timer.ms();
+  return RTMI_OK;
+}
+
+}  // namespace
+
+extern "C" int rtmi_render_accumulate(rtmi_scene* s, const rtmi_camera* cam, const rtmi_render_params* p, float* dev_xyz_sum,
+                                      void* stream_, rtmi_stats* stats) {
+  if (int rc = check_scene(s)) return rc;
+  RenderPlan r;
+  if (int rc = plan_render(s, cam, p, dev_xyz_sum, r)) return rc;
+  rtmi_ctx* ctx = s->ctx;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  Timer timer;
+  const uint32_t n_samples = r.s_end - r.s_begin;
+  if (r.n_tiles == 0 || n_samples == 0) { s->last_stats = nullptr; if (stats) *stats = s->pending; return RTMI_OK; }
+
+  const uint64_t per_tile = uint64_t(r.T) * r.T;
+  uint32_t tiles_per_batch = 0, samples_per_batch = 0;
+  for (;;) {
+    const uint64_t cap = std::max<uint64_t>(ctx->max_batch_paths, per_tile);
+    tiles_per_batch = uint32_t(std::min<uint64_t>(r.n_tiles, cap / per_tile));
+    samples_per_batch = uint32_t(std::min<uint64_t>(n_samples, std::max<uint64_t>(1, cap / (tiles_per_batch * per_tile))));
+    const size_t batch_paths = size_t(tiles_per_batch) * per_tile * samples_per_batch;
+    const int rc = ensure_workspace(ctx, batch_paths, samples_per_batch, r.deep, r.want_queues);
+    if (rc == RTMI_OK) break;
+    // The default batch is sized for an otherwise empty 288 GB device. If the workspace does not fit, halve the
+    // batch (the image does not depend on it) rather than fail; a caller-chosen cap is never second-guessed.
+    if (rc != RTMI_OOM || !ctx->batch_is_default || ctx->max_batch_paths <= (1ull << 20)) return rc;
+    (void)hipGetLastError();
+    ctx->release_workspace();
+    ctx->max_batch_paths >>= 1;
+  }
+  if (int rc = ctx->tiles.reserve(size_t(r.n_tiles) * sizeof(uint32_t))) return rc;
+  ctx->ws.tiles = ctx->tiles.as<uint32_t>();
+  if (int rc = render_batches(s, ctx->ws, cam, p, r, tiles_per_batch, samples_per_batch, dev_xyz_sum, stream, timer)) return rc;
   if (stats) {
-    if (clock.on || s->counting) return rtmi_render_collect_stats(s, stream_, stats);
+    if ((p->flags & RTMI_FLAG_TIME_KERNELS) || s->counting) return rtmi_render_collect_stats(s, stream_, stats);
     *stats = s->pending;
   }
   return RTMI_OK;
@@ -822,9 +880,9 @@ extern "C" int rtmi_render_collect_stats(rtmi_scene* s, void* stream_, rtmi_stat
   if (!stats) return fail(RTMI_BAD_ARG, "stats is NULL");
   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream_)));
   *stats = s->pending;
-  if (s->ctx->stats.p) {
+  if (s->last_stats) {
     DeviceStats h;
-    HIP_TRY(hipMemcpy(&h, s->ctx->stats.p, sizeof h, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&h, s->last_stats, sizeof h, hipMemcpyDeviceToHost));
     if (h.overflow)
       return fail(RTMI_INTERNAL, "a path-queue region overflowed and paths were dropped: the image of this render is incomplete "
                                  "(internal sizing error; please report the scene and the batch size)");
