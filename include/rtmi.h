@@ -202,6 +202,18 @@ int rtmi_render(rtmi_scene* scene, const rtmi_camera* cam, const rtmi_render_par
  * finish with rtmi_tonemap. Asynchronous on `stream` unless RTMI_FLAG_TIME_KERNELS is set. */
 int rtmi_render_accumulate(rtmi_scene* scene, const rtmi_camera* cam, const rtmi_render_params* params,
                            float* dev_xyz_sum, void* stream, rtmi_stats* stats);
+/* rtmi_render_accumulate for callers that cannot allocate device memory: code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc. It has no counterpart in the reference. The work, the arguments and the bits
+ * added to dev_xyz_sum are those of rtmi_render_accumulate, but the path queues, traversal list, emit queue, per-slot
+ * contributions, fill counters, device statistics and tile list live in a static 64 MiB device array that every GPU
+ * the library runs on holds from the moment the library is loaded, and the call makes no hipMalloc, hipFree or other
+ * allocating call. The render is cut into batches of at most 2^17 path slots (many more launches than the allocating
+ * entry point needs, so it is slower). Limits, reported as RTMI_UNSUPPORTED: tile_size * tile_size <= 2^17 (tile_size
+ * <= 360), at most 2^18 tiles in the call's share, no RTMI_FLAG_TIME_KERNELS. Every call on a GPU uses that GPU's one
+ * array, whatever the context or scene: calls that overlap in time on one GPU race; calls on one stream, or otherwise
+ * ordered, are safe. rtmi_render_collect_stats works after it as after rtmi_render_accumulate. */
+int rtmi_render_accumulate_noalloc(rtmi_scene* scene, const rtmi_camera* cam, const rtmi_render_params* params,
+                                   float* dev_xyz_sum, void* stream);
 /* Fills *stats with the counters of the last render_accumulate on `scene` once its stream work
  * has completed (synchronises the stream). */
 int rtmi_render_collect_stats(rtmi_scene* scene, void* stream, rtmi_stats* stats);

@@ -96,6 +96,7 @@ SYMBOLS = {
     "rtmi_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "rtmi_render_accumulate": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
                                          C.POINTER(Stats)]),
+    "rtmi_render_accumulate_noalloc": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p]),
     "rtmi_render_collect_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "rtmi_tonemap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
 }

@@ -151,6 +151,11 @@ class Scene:
         L.check(L.lib().rtmi_render_accumulate(self.handle, C.byref(cam), C.byref(params), C.c_void_p(xyz_sum_ptr),
                                                C.c_void_p(stream), None))
 
+    def render_accumulate_noalloc(self, cam, params, xyz_sum_ptr, stream=0):
+        """render_accumulate in the library's static scratch array: no device allocation (asynchronous)."""
+        L.check(L.lib().rtmi_render_accumulate_noalloc(self.handle, C.byref(cam), C.byref(params), C.c_void_p(xyz_sum_ptr),
+                                                       C.c_void_p(stream)))
+
     def collect_stats(self, stream=0):
         st = L.Stats()
         L.check(L.lib().rtmi_render_collect_stats(self.handle, C.c_void_p(stream), C.byref(st)))

@@ -66,8 +66,31 @@ struct DeviceStats { unsigned long long bounce_segments; TraversalCounters trav;
 
 }  // namespace
 
+// Scratch of rtmi_render_accumulate_noalloc: the workspace of one batch of at most kStaticBatchPaths path slots (both path
+// queues with the room for paths longer than 16 hits, the level-0 traversal list, the emit queue, the per-slot
+// contributions, the fill counters, the device statistics) and the tile list of one render. Every GPU the library runs
+// on holds its own copy of this array, at its own address, for the life of the process.
+constexpr size_t kStaticBatchPaths = size_t(1) << 17;
+constexpr uint32_t kStaticMaxSamplesPerBatch = 2 * kShards;     // keeps the queues' chunk slack at its default (region_chunks)
+constexpr size_t kStaticMaxTiles = size_t(1) << 18;             // tiles of one call's share (4K at 16 x 16: 32 400)
+constexpr size_t kStaticScratchBytes = size_t(64) << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+namespace {
+
+// This device's address of the scratch array (the array's name is only a host-side handle for these lookups).
+int static_scratch_address(unsigned char** out) {
+  void* p = nullptr;
+  HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+  if (!p) return fail(RTMI_HIP_ERROR, "hipGetSymbolAddress returned a null address for the static scratch array");
+  *out = static_cast<unsigned char*>(p);
+  return RTMI_OK;
+}
+
+}  // namespace
+
 // Device memory one batch of launches works in, beyond the caller's inputs and outputs. A context owns one that grows
-// on demand (ensure_workspace).
+// on demand (ensure_workspace); rtmi_render_accumulate_noalloc uses one carved out of a static device array.
 struct Workspace {
   PathQueue queue[2]{};
   size_t queue_entries = 0;       // entries of each path queue (kShards regions of queue_entries / kShards)
@@ -93,6 +116,7 @@ struct rtmi_ctx {
   DevBuf emit_mem, mesh_list;
   bool batch_is_default = true;   // max_batch_paths was not chosen by the caller: it may shrink if memory is short
   bool inline_emit = false;       // RTMI_INLINE_EMIT (read once, when the context is created): no emit queue, for A/B measurements
+  unsigned char* scratch = nullptr;  // this device's copy of the static scratch array (rtmi_render_accumulate_noalloc)
   void release_workspace() {
     for (DevBuf* b : {&queue_mem[0], &queue_mem[1], &contrib, &emit_mem, &mesh_list}) b->release();
     ws.queue_entries = 0; ws.queue_deep = false; ws.emit_paths = 0; ws.emit_deep = false;
@@ -424,6 +448,7 @@ extern "C" int rtmi_ctx_create(int device_id, uint64_t max_batch_paths, rtmi_ctx
   if (ctx->max_batch_paths > (1ull << 30)) ctx->max_batch_paths = 1ull << 30;
   ctx->inline_emit = getenv("RTMI_INLINE_EMIT") != nullptr;
   HIP_TRY(upload_constants(spectrum_tables()));
+  if (int rc = static_scratch_address(&ctx->scratch)) return rc;
   *out = ctx.release();
   return RTMI_OK;
 }
@@ -873,6 +898,56 @@ extern "C" int rtmi_render_accumulate(rtmi_scene* s, const rtmi_camera* cam, con
     *stats = s->pending;
   }
   return RTMI_OK;
+}
+
+// ================================================================================ render without allocating
+
+namespace {
+
+// Lays the workspace out in `base` (kStaticScratchBytes, 256-byte aligned). Returns false if it does not fit.
+bool carve_static_workspace(unsigned char* base, Workspace& ws) {
+  size_t at = 0;
+  auto take = [&](size_t bytes) { void* r = base + at; at += (bytes + 255) & ~size_t(255); return r; };
+  const size_t entries = queue_entries(kStaticBatchPaths, 0);
+  for (int i = 0; i < 2; ++i) ws.queue[i] = carve_queue(take(queue_bytes(entries, true)), entries, true);
+  ws.queue_entries = entries; ws.queue_deep = true;
+  ws.mesh_list = static_cast<uint32_t*>(take(entries * sizeof(uint32_t)));
+  const size_t region = emit_entries_for(kStaticBatchPaths);
+  ws.emit = carve_emit(take(emit_bytes(region, true)), region, true);
+  ws.emit_region_entries = uint32_t(region); ws.emit_paths = kStaticBatchPaths; ws.emit_deep = true;
+  ws.contrib = static_cast<float*>(take(kStaticBatchPaths * 3 * sizeof(float)));
+  ws.counts = static_cast<uint32_t*>(take(kCountBytes));
+  ws.stats = static_cast<DeviceStats*>(take(sizeof(DeviceStats)));
+  ws.tiles = static_cast<uint32_t*>(take(kStaticMaxTiles * sizeof(uint32_t)));
+  return at <= kStaticScratchBytes;
+}
+
+}  // namespace
+
+extern "C" int rtmi_render_accumulate_noalloc(rtmi_scene* s, const rtmi_camera* cam, const rtmi_render_params* p, float* dev_xyz_sum,
+                                              void* stream_) {
+  if (int rc = check_scene(s)) return rc;
+  RenderPlan r;
+  if (int rc = plan_render(s, cam, p, dev_xyz_sum, r)) return rc;
+  if (p->flags & RTMI_FLAG_TIME_KERNELS) return fail(RTMI_UNSUPPORTED, "RTMI_FLAG_TIME_KERNELS creates HIP events, which allocates; not available here");
+  const uint64_t per_tile = uint64_t(r.T) * r.T;
+  if (per_tile > kStaticBatchPaths)
+    return fail(RTMI_UNSUPPORTED, "tile_size %u: one tile (%llu paths) exceeds the static workspace's batch of %zu path slots",
+                r.T, (unsigned long long)per_tile, kStaticBatchPaths);
+  if (r.n_tiles > kStaticMaxTiles)
+    return fail(RTMI_UNSUPPORTED, "%u tiles in this call's share; the static workspace lists at most %zu (use larger tiles or a tile partition)",
+                r.n_tiles, kStaticMaxTiles);
+  rtmi_ctx* ctx = s->ctx;
+  if (!ctx->scratch) return fail(RTMI_INTERNAL, "the context has no static scratch address");
+  Workspace ws;
+  if (!carve_static_workspace(ctx->scratch, ws)) return fail(RTMI_INTERNAL, "the static workspace layout exceeds the scratch array");
+  Timer timer;
+  const uint32_t n_samples = r.s_end - r.s_begin;
+  if (r.n_tiles == 0 || n_samples == 0) { s->last_stats = nullptr; return RTMI_OK; }
+  const uint32_t tiles_per_batch = uint32_t(std::min<uint64_t>(r.n_tiles, kStaticBatchPaths / per_tile));
+  const uint32_t samples_per_batch = uint32_t(std::min<uint64_t>(std::min<uint32_t>(n_samples, kStaticMaxSamplesPerBatch),
+                                                                 std::max<uint64_t>(1, kStaticBatchPaths / (tiles_per_batch * per_tile))));
+  return render_batches(s, ws, cam, p, r, tiles_per_batch, samples_per_batch, dev_xyz_sum, static_cast<hipStream_t>(stream_), timer);
 }
 
 extern "C" int rtmi_render_collect_stats(rtmi_scene* s, void* stream_, rtmi_stats* stats) {
