@@ -7,11 +7,17 @@ tone mapping. With N > 1 ranks (torch.distributed over RCCL, one process per GPU
 renders its own `spp` samples per pixel of an N*spp job (sample-range partition, weak scaling) and
 one reduce merges the per-pixel XYZ sums. Prints ONE JSON line on rank 0.
 
-  python bench.py --gpus 1 --steps 3 --warmup 1
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus 8            # starts its own 8 ranks (or run it under torch.distributed.run)
+
+Order of a run: the CPU baseline (rank 0 of a 1-GPU run only), W untimed warm-up steps, K timed steps with no
+instrumentation at all (one fence on either side), then untimed instrumented steps (HIP events around every launch;
+exact traversal counts) from which the roofline terms are formed.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -20,83 +26,279 @@ ROOT = Path(__file__).resolve().parent
 sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, ~8 TB/s
-NODE_BYTES, TRI_BYTES = 64, 80
+N_SIMD, WAVE = 256 * 4, 64   # 256 CUs x 4 SIMDs, 64 lanes per wave
+MAX_CLOCK_GHZ = 2.4
+L2_BYTES, INFINITY_CACHE_BYTES = 32 << 20, 256 << 20
+NODE_BYTES, TRI_BYTES = 64, 80      # a BVH node; a mesh triangle (f64 vertices + file-order index)
 # Algorithmic bytes per unit of the two kernels a roofline is quoted for:
 #   traverse_kernel, per listed ray: list entry (4) + ray origin and direction (48) + the hit record it folds its result
 #     into (12 read, 28 written) + the BVH nodes and triangles that ray visits
 #   bounce_kernel (scenes without meshes), per segment: one path-state record read and one written (6 f64 + 4 u32 + 16
 #     chain bytes each)
 TRAVERSE_RAY_BYTES = 4 + 48 + 12 + 28
-# flops model of the same units: 40 per node visit, 55 per triangle test, 180 + 45 per analytic object for shading
+STATE_BYTES = 80
+# flop model of the same units (FP64-equivalent): 40 per node visit, 55 per triangle test, 180 + 45 per analytic object
 NODE_FLOPS, TRI_FLOPS, SHADE_FLOPS = 40, 55, 180 + 6 * 45
 VALU_F64_PEAK_TFLOPS = 78.6
-STATE_BYTES = 80
 
 WORKLOADS = {
     # the headline configuration: Suzanne (968 triangles) + emitter + ground spheres, 1920x1080, 64 spp
     "suzanne_1080p_64spp": dict(recipe="scene2", width=1920, height=1080, spp=64, depth=10),
     "suzanne_specular_1080p_64spp": dict(recipe="scene2", width=1920, height=1080, spp=64, depth=10, specular_mesh=True),
     "scene1_400x225_100spp": dict(recipe="scene1", width=400, height=225, spp=100, depth=10),
+    "scene2_850x480_100spp": dict(recipe="scene2", width=850, height=480, spp=100, depth=10),
     "scene3_720p_100spp": dict(recipe="scene3", width=1280, height=720, spp=100, depth=10),
+    # the 1 048 576-triangle procedural mesh at 4K: the full 256 spp, and a 16 spp cut for quick runs
+    "mesh1m_4k_256spp": dict(recipe="synthetic_mesh_scene", width=3840, height=2160, spp=256, depth=10),
     "mesh1m_4k_16spp": dict(recipe="synthetic_mesh_scene", width=3840, height=2160, spp=16, depth=10),
-    # scene3's layout with glossy / dielectric extension materials, depth 32 (16 of the configuration's 1024 spp)
+    # scene3's layout with glossy / dielectric extension materials, depth 32: the full 1024 spp and a 16 spp cut
+    "scene3_extended_4k_1024spp": dict(recipe="scene3_extended", width=3840, height=2160, spp=1024, depth=32),
     "scene3_extended_4k_16spp": dict(recipe="scene3_extended", width=3840, height=2160, spp=16, depth=32),
 }
 
 
-def build_scene(ctx, w, hit_rule, from_rgb=None, library=True):
+def build_scene(ctx, w, hit_rule, from_rgb=None, library=True, **override):
     from raytracing_amd import api, scenes
     kw = {k: v for k, v in w.items() if k in ("width", "height", "specular_mesh")}
+    kw.update(override)
     builder, cam_args = getattr(scenes, w["recipe"])(from_rgb=from_rgb, **kw)
     if library:
         return api.Scene(ctx, *builder.arrays(), hit_rule=hit_rule), api.camera_new(*cam_args)
     return builder, cam_args
 
 
-def cpu_baseline(w, hit_rule, spp_sample, threads):
-    """The CPU oracle (linear scans, the reference's algorithm) on the first `spp_sample` samples per
-    pixel of the same scene and camera, on this machine's host cores."""
+def cpu_baseline(w, hit_rule, threads, target_seconds=12.0):
+    """The CPU oracle (linear scans over objects and triangles: the reference's algorithm) on a bounded sample of the
+    same workload, on this machine's host cores. The sample keeps the camera and the scene and cuts samples per pixel
+    first, then (for the million-triangle mesh, where one segment costs a million triangle tests) the resolution: the
+    same field of view through fewer pixels is a uniform subsample of the image's paths."""
     import _oracle as O
-    builder, cam_args = build_scene(None, w, hit_rule, from_rgb=O.from_rgb, library=False)
+    mesh = w["recipe"] == "synthetic_mesh_scene"
+    div = 60 if mesh else 1
+    override = dict(width=w["width"] // div, height=w["height"] // div) if div > 1 else {}
+    builder, cam_args = build_scene(None, w, hit_rule, from_rgb=O.from_rgb, library=False, **override)
     scene = O.Scene(*builder.arrays(), hit_rule=hit_rule)
     cam = O.camera(*cam_args)
-    _, _, _, st = scene.render(cam, O.INT_RANDOM_WALK, w["depth"], w["spp"], seed=0, sample_range=(0, spp_sample),
-                               threads=threads, want_lin=False)
-    return st.segments / st.seconds / 1e6, st.seconds, st.segments
+    spp = 1
+    total_seg, total_s, done = 0, 0.0, 0
+    # grow the sample until it has run for about target_seconds (each leg renders samples [done, done + spp))
+    while done < w["spp"] and total_s < target_seconds:
+        spp = min(spp, w["spp"] - done)
+        _, _, _, st = scene.render(cam, O.INT_RANDOM_WALK, w["depth"], w["spp"], seed=0, sample_range=(done, done + spp),
+                                   threads=threads, want_lin=False)
+        total_seg += st.segments; total_s += st.seconds; done += spp
+        if st.seconds > 0:
+            spp = max(1, min(int(spp * min(4.0, 0.5 * target_seconds / st.seconds)), 64))
+    what = "same scene and camera%s, samples [0,%d) of %d per pixel: %d segments in %.1f s" % (
+        " through %dx%d pixels (1/%d of the image's)" % (cam.width, cam.height, div * div) if div > 1 else "", done, w["spp"],
+        total_seg, total_s)
+    return total_seg / total_s / 1e6, what
+
+
+# ------------------------------------------------------------------------------------------- launcher
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` typed without a launcher: start N fresh rank processes (one per GPU) and wait.
+    This parent never touches the GPU or imports torch; rank 0 prints the JSON line on the stdout it inherits."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env))
+    rc = 0
+    live = set(range(n))
+    while live:
+        time.sleep(0.2)
+        for r in list(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                sys.stderr.write("bench.py: rank %d exited with %d; stopping the other ranks\n" % (r, code))
+                for o in live:
+                    procs[o].terminate()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------- roofline
+
+def committed_counters(workload, rule, kernel):
+    """Per-launch hardware counters of `kernel` from the rocprofv3 PMC passes of this workload committed under
+    profiles/ (tools/pmc_summary.py writes the file): HBM bytes, VALU-busy and lane-utilisation fractions."""
+    f = ROOT / "profiles" / "pmc_summary.json"
+    try:
+        d = json.loads(f.read_text())
+        return d.get("%s/%s" % (workload, rule), {}).get(kernel)
+    except Exception:
+        return None
+
+
+def roofline(args, w, scene_info, counted, timed, world):
+    """Every term a launch of the dominant kernel could be bound by, and the one that binds.
+
+      hbm        counter bytes per launch (FETCH_SIZE doubled + WRITE_SIZE, committed PMC pass) / live launch time / 8 TB/s
+      valu       lane-instructions per launch (SQ_THREAD_CYCLES_VALU, committed PMC pass) / live launch time, against one
+                 wave64 vector instruction per SIMD per 4 cycles at the clock the profiled launch ran at -- what
+                 SQ_ACTIVE_INST_VALU charges every instruction and what a binary64 instruction really takes; a binary32
+                 instruction can issue in 2, so for binary32-heavy code this ceiling is low by up to 2x and the fraction
+                 high by as much (frac_if_all_binary32 is the other end)
+      algorithmic  every node, triangle and record fetch charged to memory (the per-unit byte model): what the traffic
+                 would be with no cache at all; it exceeds the HBM term by the cache hit ratio and is a fraction of a
+                 roof only when the tree does not fit the 256 MiB Infinity Cache
+    """
+    two_kernel = timed["traverse_launches"] > 0
+    if two_kernel:
+        kernel, unit_name = "traverse_kernel", "ray"
+        units = timed["mesh_rays"]
+        per_unit = max(1, counted["mesh_rays"])
+        base_bytes, k_ms, k_launches = TRAVERSE_RAY_BYTES, timed["ms_traverse"], timed["traverse_launches"]
+    else:
+        kernel, unit_name = "bounce_kernel", "segment"
+        units = timed["segments"]
+        per_unit = max(1, counted["segments"])
+        base_bytes, k_ms, k_launches = 2 * STATE_BYTES, timed["ms_kernels"], timed["launches"]
+    nodes_per_unit = counted["nodes_visited"] / per_unit
+    tris_per_unit = counted["prims_tested"] / per_unit
+    bytes_per_unit = base_bytes + nodes_per_unit * NODE_BYTES + tris_per_unit * TRI_BYTES
+    avg_ms = k_ms / max(1, k_launches)
+    secs = avg_ms * 1e-3
+    units_per_launch = units / max(1, k_launches)
+    algorithmic_gbs = units_per_launch * bytes_per_unit / secs / 1e9 if secs > 0 else 0.0
+    flops_per_unit = nodes_per_unit * NODE_FLOPS + tris_per_unit * TRI_FLOPS + (0 if two_kernel else SHADE_FLOPS)
+    model_tflops = units_per_launch * flops_per_unit / secs / 1e12 if secs > 0 else 0.0
+    tree_bytes = scene_info["node_bytes"] + scene_info["triangle_bytes"]
+    terms = {"algorithmic": {"achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algorithmic_gbs / HBM_PEAK_GBS,
+                             "bytes_per_unit": bytes_per_unit, "counts_as_hbm_roof": tree_bytes > INFINITY_CACHE_BYTES,
+                             "tree_bytes": tree_bytes}}
+    pmc = committed_counters(args.workload, args.rule, kernel)
+    traffic = None
+    if pmc and secs > 0:
+        traffic = pmc.get("hbm_bytes_per_launch")
+        if traffic is not None:
+            gbs = traffic / secs / 1e9
+            terms["hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+        if pmc.get("lane_instructions_per_launch"):
+            clock = pmc.get("clock_ghz") or MAX_CLOCK_GHZ
+            peak = N_SIMD * WAVE * clock / 4.0 / 1e3                       # T lane-instructions / s
+            ach = pmc["lane_instructions_per_launch"] / secs / 1e12
+            terms["valu"] = {"achieved": ach, "peak": peak, "unit": "Tlane-instr/s", "frac": ach / peak,
+                             "frac_if_all_binary32": ach / (2.0 * peak), "valu_busy": pmc.get("valu_busy"),
+                             "lane_utilisation": pmc.get("lane_utilisation"), "clock_ghz": clock,
+                             "profiled_launch_ms": pmc.get("launch_ms")}
+    candidates = {k: v for k, v in terms.items() if k != "algorithmic" or v["counts_as_hbm_roof"]}
+    if "valu" not in terms:   # no counter pass committed for this workload: the flop model stands in for the VALU term
+        candidates["valu_model"] = {"achieved": model_tflops, "peak": VALU_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": model_tflops / VALU_F64_PEAK_TFLOPS}
+        terms["valu_model"] = candidates["valu_model"]
+    bound = max(candidates, key=lambda k: candidates[k]["frac"])
+    b = candidates[bound]
+    return {"bound": {"algorithmic": "hbm", "valu_model": "valu"}.get(bound, bound), "achieved": b["achieved"], "peak": b["peak"],
+            "unit": b["unit"], "frac": b["frac"], "traffic": traffic, "binding_term": bound,
+            "kernel": kernel, "launches": k_launches, "avg_launch_ms": avg_ms, "unit_of_work": unit_name,
+            "units_per_launch": units_per_launch, "nodes_per_unit": nodes_per_unit, "triangles_per_unit": tris_per_unit,
+            "flops_per_unit": flops_per_unit, "all_kernels_ms_per_step": timed["ms_kernels"] / max(1, timed["steps"]),
+            "all_launches": timed["launches"], "terms": terms,
+            "counters_from": "profiles/pmc_summary.json" if pmc else None}
+
+
+# ------------------------------------------------------------------------------------------- one rank
+
+def dry_run(args, world, rank):
+    """The launcher, the rendezvous and the merge without a GPU (gloo): every rank contributes rank + 1 to its share of
+    a small buffer, rank 0 checks the sum and prints a line of the usual shape."""
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import parallel
+    if world > 1:
+        dist.init_process_group("gloo")
+    n = 96 * 54 * 3
+    t0 = time.perf_counter()
+    acc = torch.full((n,), float(rank + 1), dtype=torch.float32)
+    share = parallel.rank_share(args.partition, 64 * world, rank, world)
+    parallel.merge_sums(acc, 0)
+    if world > 1:
+        dist.barrier()
+    ms = (time.perf_counter() - t0) * 1e3
+    per_rank = [None] * world
+    if world > 1:
+        dist.all_gather_object(per_rank, {"rank": rank, "ms": ms, "share": share})
+    else:
+        per_rank = [{"rank": 0, "ms": ms, "share": share}]
+    if rank == 0:
+        ok = bool((acc == world * (world + 1) / 2).all())
+        print(json.dumps({"metric": "Mpath-segments/sec (whole node)", "value": 0.0, "unit": "Mseg/s", "n_gpus": world, "dry_run": True,
+                          "world_size": dist.get_world_size() if world > 1 else 1, "merge_ok": ok, "per_rank": per_rank,
+                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="suzanne_1080p_64spp", choices=sorted(WORKLOADS))
     ap.add_argument("--rule", default="first_index", choices=["first_index", "nearest"])
     ap.add_argument("--partition", default="samples", choices=["samples", "tiles"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every core this process may use)")
     ap.add_argument("--batch-paths", type=int, default=0, help="path slots per batch of launches (0 = library default)")
-    ap.add_argument("--cpu-spp", type=int, default=0, help="samples per pixel of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise the launcher, the rendezvous and the merge over gloo")
     args = ap.parse_args()
+
+    n = max(1, args.gpus)
+    if n > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(n, sys.argv[1:]))       # nothing above this line has touched the GPU
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != n:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, world, rank)
+
+    w = WORKLOADS[args.workload]
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # first, while the GPU is idle: it is the long leg of the run
+        from raytracing_amd import _lib as L0
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        share = int(os.environ.get("OMP_NUM_THREADS", "0")) or cores     # the box's CPU share when it is smaller than the machine
+        threads = args.cpu_threads or max(1, min(cores, share))
+        rule0 = L0.HIT_FIRST_INDEX if args.rule == "first_index" else L0.HIT_NEAREST
+        v, what = cpu_baseline(w, rule0, threads)
+        cpu = {"value": v, "unit": "Mseg/s", "cores": threads, "kind": "port", "sample": what,
+               "host_cores_visible": os.cpu_count(), "cores_usable": max(1, min(cores, share))}
 
     import torch
     import torch.distributed as dist
     from raytracing_amd import api, parallel, _lib as L
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(1, args.gpus):
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" %
-                         (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
 
-    w = WORKLOADS[args.workload]
     hit_rule = L.HIT_FIRST_INDEX if args.rule == "first_index" else L.HIT_NEAREST
     ctx = api.Context(local_rank, args.batch_paths)
+    t_build = time.perf_counter()
     scene, cam = build_scene(ctx, w, hit_rule)
+    build_s = time.perf_counter() - t_build
     width, height, spp, depth = cam.width, cam.height, w["spp"], w["depth"]
     spp_job = spp * world if args.partition == "samples" else spp     # weak scaling in samples
     stream = torch.cuda.current_stream().cuda_stream
@@ -121,57 +323,43 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # one instrumented step: exact traversal counts for the algorithmic-bytes model (not timed)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()                                # no instrumentation, no host synchronisation inside the timed region
+    fence()
+    elapsed = time.perf_counter() - t0
+    seg_step = scene.collect_stats(stream)["segments"]     # exact, from the fill counters of the last step
+    segments = seg_step * args.steps
+
+    # untimed: exact traversal counts, then HIP events around every launch (on `stream`) for the roofline terms
     step(L.FLAG_COUNT_TRAVERSAL)
     counted = scene.collect_stats(stream)
     fence()
-
-    kernel_ms, launches, segments, trav_ms, trav_launches, mesh_rays = 0.0, 0, 0, 0.0, 0, 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(L.FLAG_TIME_KERNELS)             # HIP events around every closest-hit launch, on `stream`
+    timed = dict(ms_kernels=0.0, launches=0, segments=0, ms_traverse=0.0, traverse_launches=0, mesh_rays=0, steps=0)
+    t1 = time.perf_counter()
+    for _ in range(max(1, min(args.steps, 5))):
+        step(L.FLAG_TIME_KERNELS)
         st = scene.collect_stats(stream)
-        kernel_ms += st["ms_kernels"]; launches += st["launches"]; segments += st["segments"]
-        trav_ms += st["ms_traverse"]; trav_launches += st["traverse_launches"]; mesh_rays += st["mesh_rays"]
+        for k in ("ms_kernels", "launches", "segments", "ms_traverse", "traverse_launches", "mesh_rays"):
+            timed[k] += st[k]
+        timed["steps"] += 1
     fence()
-    elapsed = time.perf_counter() - t0
+    instrumented_ms = (time.perf_counter() - t1) / timed["steps"] * 1e3
 
     t = torch.tensor([elapsed, float(segments)], dtype=torch.float64, device=device)
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        gathered = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([elapsed / args.steps * 1e3], dtype=torch.float64, device=device))
+        per_rank_ms = [float(g[0]) for g in gathered]
         elapsed = float(tmax[0])
     total_segments = float(t[1])
 
     if rank == 0:
-        seg_per_step = counted["segments"]
-        if trav_launches:       # two-kernel pipeline: the traversal kernel dominates
-            kernel, unit_name = "traverse_kernel", "ray"
-            units = mesh_rays
-            nodes_per_unit = counted["nodes_visited"] / max(1, counted["mesh_rays"])
-            tris_per_unit = counted["prims_tested"] / max(1, counted["mesh_rays"])
-            bytes_per_unit = TRAVERSE_RAY_BYTES + nodes_per_unit * NODE_BYTES + tris_per_unit * TRI_BYTES
-            k_ms, k_launches = trav_ms, trav_launches
-        else:
-            kernel, unit_name = "bounce_kernel", "segment"
-            units = segments
-            nodes_per_unit = counted["nodes_visited"] / max(1, seg_per_step)
-            tris_per_unit = counted["prims_tested"] / max(1, seg_per_step)
-            bytes_per_unit = 2 * STATE_BYTES + nodes_per_unit * NODE_BYTES + tris_per_unit * TRI_BYTES
-            k_ms, k_launches = kernel_ms, launches
-        avg_launch_ms = k_ms / max(1, k_launches)
-        units_per_launch = units / max(1, k_launches)
-        achieved_gbs = (units_per_launch * bytes_per_unit) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        flops_per_unit = nodes_per_unit * NODE_FLOPS + tris_per_unit * TRI_FLOPS + (0 if trav_launches else SHADE_FLOPS)
-        valu_tflops = (units_per_launch * flops_per_unit) / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
-        traffic = None
-        tfile = ROOT / "profiles" / "hbm_traffic.json"
-        if tfile.exists():   # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
-            try:
-                traffic = json.loads(tfile.read_text()).get(args.workload, {}).get(kernel, {}).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        info = scene.info()
         out = {
             "metric": "Mpath-segments/sec (whole node)",
             "value": total_segments / elapsed / 1e6,
@@ -185,31 +373,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "width": width, "height": height, "spp_per_gpu": spp if args.partition == "samples" else None,
                        "spp_job": spp_job, "max_depth": depth, "integrator": "RandomWalk", "hit_rule": args.rule,
-                       "partition": args.partition, "mesh_triangles": scene.info()["n_mesh_triangles"],
-                       "segments_per_step_per_gpu": seg_per_step},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel, "launches": k_launches, "avg_launch_ms": avg_launch_ms,
-                         "unit_of_work": unit_name, "bytes_per_unit": bytes_per_unit, "nodes_per_unit": nodes_per_unit,
-                         "triangles_per_unit": tris_per_unit, "units_per_launch": units_per_launch,
-                         "all_kernels_ms_per_step": kernel_ms / args.steps, "all_launches": launches,
-                         "note": "algorithmic bytes charge every BVH node and triangle fetch to memory; when the scene is "
-                                 "cache-resident they are cache hits, so frac can exceed 1 while `traffic` (HBM bytes per "
-                                 "launch from the committed PMC passes) stays far below it",
-                         # the other term of the model: FP64-equivalent vector flops of the same launches
-                         "valu": {"flops_per_unit": flops_per_unit, "achieved": valu_tflops, "peak": VALU_F64_PEAK_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": valu_tflops / VALU_F64_PEAK_TFLOPS}},
+                       "partition": args.partition, "mesh_triangles": info["n_mesh_triangles"],
+                       "segments_per_step_per_gpu": seg_step, "scene_build_s": build_s,
+                       "bvh_build_s": info.get("bvh_build_ms", 0.0) / 1e3},
+            "world_size": dist.get_world_size() if world > 1 else 1,
+            "per_rank_ms_per_step": per_rank_ms,
+            "ms_per_step_instrumented": instrumented_ms,
+            "roofline": roofline(args, w, info, counted, timed, world),
+            "cpu_baseline": cpu,
         }
-        if not args.no_cpu_baseline:
-            threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
-            cpu_spp = args.cpu_spp or (1 if w["recipe"] == "synthetic_mesh_scene" else max(1, min(spp, 16)))
-            if w["recipe"] == "synthetic_mesh_scene":
-                out["cpu_baseline"] = None  # linear scans over 1M triangles: minutes per 1e5 segments; not run by default
-            else:
-                v, secs, segs = cpu_baseline(w, hit_rule, cpu_spp, threads)
-                out["cpu_baseline"] = {"value": v, "unit": "Mseg/s", "cores": threads, "kind": "port",
-                                       "sample": "same scene and camera, samples [0,%d) of %d per pixel: %d segments in %.1f s"
-                                                 % (cpu_spp, spp, segs, secs)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -143,6 +143,8 @@ typedef struct {
 typedef struct {
   uint32_t n_nodes, max_depth, n_mesh_triangles, n_spectra;
   uint64_t node_bytes, triangle_bytes;
+  double bvh_build_ms;   /* host wall time rtmi_scene_create spent building the BVHs of the scene's models */
+  double upload_ms;      /* ... and flattening the rest and copying everything to the device */
 } rtmi_scene_info;
 
 typedef struct rtmi_ctx rtmi_ctx;

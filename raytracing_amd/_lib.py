@@ -69,7 +69,7 @@ class Stats(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("max_depth", C.c_uint32), ("n_mesh_triangles", C.c_uint32), ("n_spectra", C.c_uint32),
-                ("node_bytes", C.c_uint64), ("triangle_bytes", C.c_uint64)]
+                ("node_bytes", C.c_uint64), ("triangle_bytes", C.c_uint64), ("bvh_build_ms", C.c_double), ("upload_ms", C.c_double)]
 
 
 # every symbol include/rtmi.h declares: name -> (restype, argtypes)

@@ -539,6 +539,8 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
       (d->n_materials && !d->materials))
     return fail(RTMI_BAD_ARG, "a non-empty array is NULL");
 
+  Timer create_timer;
+  double bvh_build_ms = 0.0;
   std::vector<DevMaterial> mats(d->n_materials);
   bool extension_materials = false;
   std::vector<float> spectra;
@@ -616,7 +618,9 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
     } else if (o.kind == RTMI_OBJ_MODEL) {
       if (uint64_t(o.first) + o.count > d->n_triangles) return fail(RTMI_BAD_ARG, "object %u: triangles [%u,+%u) out of range", i, o.first, o.count);
       if (o.count >= (1u << 27)) return fail(RTMI_UNSUPPORTED, "object %u: %u triangles in one mesh", i, o.count);
+      Timer bvh_timer;
       BvhBuild bb = build_bvh(o.count ? d->triangles[o.first].v : nullptr, o.count, 4);
+      bvh_build_ms += bvh_timer.ms();
       dobj.root = uint32_t(nodes.size());
       dobj.first = uint32_t(mesh_tris.size());
       std::memcpy(dobj.center, bb.center, sizeof dobj.center);
@@ -671,6 +675,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   s->info.n_nodes = uint32_t(nodes.size()); s->info.max_depth = max_depth;
   s->info.n_mesh_triangles = uint32_t(mesh_tris.size()); s->info.n_spectra = s->dev.n_spectra;
   s->info.node_bytes = nodes.size() * sizeof(BvhNode); s->info.triangle_bytes = mesh_tris.size() * (sizeof(DevMeshTri) + sizeof(DevTriFrame));
+  s->info.bvh_build_ms = bvh_build_ms; s->info.upload_ms = create_timer.ms() - bvh_build_ms;
   *out = s.release();
   return RTMI_OK;
 }
