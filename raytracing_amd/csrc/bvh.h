@@ -23,4 +23,14 @@ struct BvhBuild {
 // never reject a triangle the exact binary64 test would accept.
 BvhBuild build_bvh(const double* tri_vertices, uint32_t n, uint32_t leaf_size);
 
+// The grid a mesh's node boxes are quantised on (relative to the mesh centre) and the nodes in the form the kernels
+// walk (rt_types.h: RT_NODES_*). Every quantised box contains the binary32 box it was made from, with at least one
+// grid step to spare on every side.
+struct QuantizedNodes {
+  float grid_lo[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1};
+  std::vector<RtWord4> words;        // 2 (SMALL, NEAREST) or 3 (WIDE) per node, in node order
+};
+QuantizedNodes quantize_nodes(const BvhBuild& build, int format);
+inline uint32_t node_words4(int format) { return format == RT_NODES_WIDE ? 3u : 2u; }
+
 }  // namespace rtmi

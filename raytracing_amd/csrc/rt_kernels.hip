@@ -182,8 +182,9 @@ __device__ __forceinline__ bool sphere_t(const DevSphere& s, V3 o, V3 d, V3 dn, 
 // The ray as the binary32 box tests see it: origin relative to an object's centre, direction and
 // its reciprocal, and delta, a bound on how far the binary32 ray can stray from the binary64 one
 // anywhere inside the object's bounding sphere (rounding of the origin, 2^-24 |o - c|, plus rounding
-// of the direction over the longest useful distance, 2^-24 (|o - c| + R)). Growing every box by delta
-// keeps the box test conservative; 2^-21 (|o - c| + R) leaves a factor of four to spare.
+// of the direction over the longest useful distance, 2^-24 (|o - c| + R)) plus the rounding of the few
+// binary32 operations that place a plane along the ray (another 2^-22 (|o - c| + R) at most). Growing
+// every box by delta keeps the box test conservative; 2^-20 (|o - c| + R) leaves a factor of two to spare.
 struct RayDir { float dx, dy, dz, ix, iy, iz; };
 struct BoxRay { float ox, oy, oz, dx, dy, dz, ix, iy, iz, delta; };
 
@@ -199,7 +200,7 @@ __device__ __forceinline__ RayDir make_ray_dir(V3 d) {
 __device__ __forceinline__ BoxRay make_box_ray(V3 o, const RayDir& d, const DevObject& ob) {
   BoxRay r;
   r.ox = float(o.x - ob.center[0]); r.oy = float(o.y - ob.center[1]); r.oz = float(o.z - ob.center[2]);
-  r.delta = 0x1.0p-21f * (fmaxf(fmaxf(fabsf(r.ox), fabsf(r.oy)), fabsf(r.oz)) + float(ob.radius) * 1.0000005f);
+  r.delta = 0x1.0p-20f * (fmaxf(fmaxf(fabsf(r.ox), fabsf(r.oy)), fabsf(r.oz)) + float(ob.radius) * 1.0000005f);
   r.dx = d.dx; r.dy = d.dy; r.dz = d.dz; r.ix = d.ix; r.iy = d.iy; r.iz = d.iz;
   return r;
 }
@@ -269,6 +270,77 @@ __device__ __forceinline__ bool model_gate_certain(const DevObject& ob, const Bo
   return tn <= tf;
 }
 
+// ------------------------------------------------------------------------------- quantised BVH nodes
+
+// How a node format (rt_types.h: RT_NODES_*) names children. `kLeaf` marks a leaf reference, `kNone` an empty slot
+// and, as the current node of a lane, "traversal finished" (it carries the leaf bit, so it also ends a node loop).
+template <int FMT> struct NodeFmt {
+  static constexpr uint32_t kWords4 = FMT == RT_NODES_WIDE ? 3u : 2u;
+  static constexpr uint32_t kLeaf = FMT == RT_NODES_SMALL ? RT_SMALL_LEAF_FLAG : RT_LEAF_FLAG;
+  static constexpr uint32_t kNone = FMT == RT_NODES_SMALL ? RT_SMALL_REF_NONE : RT_REF_NONE;
+  // a leaf reference in the common form RT_LEAF_FLAG | first << 4 | count
+  static __device__ __forceinline__ uint32_t leaf(uint32_t ref) {
+    return FMT == RT_NODES_SMALL ? (RT_LEAF_FLAG | ((ref & 0x7FFCu) << 2) | ((ref & 3u) + 1u)) : ref;
+  }
+};
+
+// The ray against a mesh's quantisation grid: a plane at level q of axis k lies at grid_lo + q * grid_step, so its
+// distance along the ray is q * (step * inv_d) + (grid_lo - o) * inv_d -- one fused multiply-add per plane, with the
+// origin moved by -+delta for the low / high planes (the box grown by the ray's delta, as in slab32). The rounding
+// of these few binary32 operations stays within the part of delta that is kept for it and within the grid step every
+// box was pushed outward by.
+struct QuantRay { float sx, sy, sz, lx, ly, lz, hx, hy, hz; };
+
+__device__ __forceinline__ QuantRay make_quant_ray(const BoxRay& r, const DevObject& ob) {
+  QuantRay q;
+  q.sx = ob.grid_step[0] * r.ix; q.sy = ob.grid_step[1] * r.iy; q.sz = ob.grid_step[2] * r.iz;
+  q.lx = (ob.grid_lo[0] - (r.ox + r.delta)) * r.ix; q.hx = (ob.grid_lo[0] - (r.ox - r.delta)) * r.ix;
+  q.ly = (ob.grid_lo[1] - (r.oy + r.delta)) * r.iy; q.hy = (ob.grid_lo[1] - (r.oy - r.delta)) * r.iy;
+  q.lz = (ob.grid_lo[2] - (r.oz + r.delta)) * r.iz; q.hz = (ob.grid_lo[2] - (r.oz - r.delta)) * r.iz;
+  return q;
+}
+
+struct Children { bool h0, h1; float tn0, tn1; uint32_t ref0, ref1, min0, min1; };
+
+__device__ __forceinline__ float q_lo16(uint32_t w) { return float(w & 0xFFFFu); }
+__device__ __forceinline__ float q_hi16(uint32_t w) { return float(w >> 16); }
+
+// Both children of the node at `np` against the ray: slab tests on the quantised planes (a zero direction component
+// gives +-inf or NaN; fminf/fmaxf drop a NaN operand, which only makes the test more permissive), the final comparison
+// allowing for the rounding of the plane distances; then the references and minimum indices in the format's form.
+template <int FMT>
+__device__ __forceinline__ Children test_children(const uint4* __restrict__ np, const QuantRay& r, float tmax) {
+  const uint4 w0 = np[0], w1 = np[1];
+  Children c;
+  {
+    const float ax = __builtin_fmaf(q_lo16(w0.x), r.sx, r.lx), bx = __builtin_fmaf(q_hi16(w0.y), r.sx, r.hx);
+    const float ay = __builtin_fmaf(q_hi16(w0.x), r.sy, r.ly), by = __builtin_fmaf(q_lo16(w0.z), r.sy, r.hy);
+    const float az = __builtin_fmaf(q_lo16(w0.y), r.sz, r.lz), bz = __builtin_fmaf(q_hi16(w0.z), r.sz, r.hz);
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    c.tn0 = tn; c.h0 = tn <= tf * 1.000002f;
+  }
+  {
+    const float ax = __builtin_fmaf(q_lo16(w0.w), r.sx, r.lx), bx = __builtin_fmaf(q_hi16(w1.x), r.sx, r.hx);
+    const float ay = __builtin_fmaf(q_hi16(w0.w), r.sy, r.ly), by = __builtin_fmaf(q_lo16(w1.y), r.sy, r.hy);
+    const float az = __builtin_fmaf(q_lo16(w1.x), r.sz, r.lz), bz = __builtin_fmaf(q_hi16(w1.y), r.sz, r.hz);
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    c.tn1 = tn; c.h1 = tn <= tf * 1.000002f;
+  }
+  if (FMT == RT_NODES_SMALL) {
+    c.ref0 = w1.z & 0xFFFFu; c.ref1 = w1.z >> 16; c.min0 = w1.w & 0xFFFFu; c.min1 = w1.w >> 16;
+  } else if (FMT == RT_NODES_NEAREST) {
+    c.ref0 = w1.z; c.ref1 = w1.w; c.min0 = 0u; c.min1 = 0u;
+  } else {
+    const uint4 w2 = np[2];
+    c.ref0 = w1.z; c.ref1 = w1.w; c.min0 = w2.x; c.min1 = w2.y;
+  }
+  c.h0 = c.h0 & (c.ref0 != NodeFmt<FMT>::kNone);   // no branch: empty slots are rare
+  c.h1 = c.h1 & (c.ref1 != NodeFmt<FMT>::kNone);
+  return c;
+}
+
 struct MeshHit { double t, t_raw; uint32_t index; uint32_t slot; };
 
 // Closest hit inside one mesh through its BVH. RULE = RT_HIT_FIRST_INDEX returns the hit
@@ -280,46 +352,41 @@ struct MeshHit { double t, t_raw; uint32_t index; uint32_t slot; };
 // Two nested loops: lanes first walk inner nodes (cheap binary32 box tests) until each holds a
 // leaf or is done, then the wave does its leaves together, so the expensive triangle code runs
 // once per leaf a lane visits instead of once per node step of the slowest lane.
-template <int RULE, bool COUNT>
+template <int FMT, int RULE, bool COUNT>
 __device__ __forceinline__ bool mesh_closest(const uint4* __restrict__ nodes, const DevMeshTri* __restrict__ tris,
                                              const DevTriFrame* __restrict__ frames, const DevObject& ob, V3 o, V3 d_built, V3 d,
                                              uint32_t* stack, MeshHit& best, uint32_t& n_nodes, uint32_t& n_prims) {
+  typedef NodeFmt<FMT> F;
   const BoxRay br = make_box_ray(o, d, ob);
   best.t = INFINITY; best.t_raw = 0.0; best.index = RT_MISS; best.slot = 0;
   if (!model_gate_certain(ob, br) && !model_gate_exact(ob.gate_lo, ob.gate_hi, o, d_built)) return false;
-  constexpr uint32_t kDone = RT_REF_NONE;  // has the leaf bit set, so it also ends the node loop
+  const QuantRay qr = make_quant_ray(br, ob);
+  constexpr uint32_t kDone = F::kNone;
   uint32_t cur = 0;
   int sp = 0;
   for (;;) {
-    while (!(cur & RT_LEAF_FLAG)) {
-      const uint4* np = nodes + size_t(cur) * 4;   // 64-byte node = 4 x 16 bytes, from LDS when the tree is staged
-      const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+    while (!(cur & F::kLeaf)) {
       if (COUNT) ++n_nodes;
-      const float lo0[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
-      const float hi0[3] = {__uint_as_float(w0.w), __uint_as_float(w1.x), __uint_as_float(w1.y)};
-      const float lo1[3] = {__uint_as_float(w1.z), __uint_as_float(w1.w), __uint_as_float(w2.x)};
-      const float hi1[3] = {__uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w)};
-      const uint32_t ref0 = w3.x, ref1 = w3.y, min0 = w3.z, min1 = w3.w;
       // nearest rule: nothing farther than the best hit so far (rounded up, with the same slack) can win
       const float tmax = RULE == RT_HIT_NEAREST ? __double2float_ru(best.t) * 1.000002f : INFINITY;
-      float tn0, tn1;
-      bool h0 = slab32(lo0, hi0, br, tmax, tn0) & (ref0 != RT_REF_NONE);   // no branch: empty slots are rare
-      bool h1 = slab32(lo1, hi1, br, tmax, tn1) & (ref1 != RT_REF_NONE);
-      if (RULE == RT_HIT_FIRST_INDEX) { h0 = h0 && min0 < best.index; h1 = h1 && min1 < best.index; }
+      const Children c = test_children<FMT>(nodes + size_t(cur) * F::kWords4, qr, tmax);   // from LDS when the tree is staged
+      bool h0 = c.h0, h1 = c.h1;
+      if (RULE == RT_HIT_FIRST_INDEX) { h0 = h0 && c.min0 < best.index; h1 = h1 && c.min1 < best.index; }
       if (h0 && h1) {
-        const bool swap = RULE == RT_HIT_FIRST_INDEX ? (min1 < min0) : (tn1 < tn0);
-        stack[(sp++) * kBlock] = swap ? ref0 : ref1;
-        cur = swap ? ref1 : ref0;
+        const bool swap = RULE == RT_HIT_FIRST_INDEX ? (c.min1 < c.min0) : (c.tn1 < c.tn0);
+        stack[(sp++) * kBlock] = swap ? c.ref0 : c.ref1;
+        cur = swap ? c.ref1 : c.ref0;
       } else if (h0) {
-        cur = ref0;
+        cur = c.ref0;
       } else if (h1) {
-        cur = ref1;
+        cur = c.ref1;
       } else {
         cur = sp ? stack[(--sp) * kBlock] : kDone;
       }
     }
     if (cur == kDone) break;
-    const uint32_t first = (cur & ~RT_LEAF_FLAG) >> 4, cnt = cur & 15u;
+    const uint32_t leaf = F::leaf(cur);
+    const uint32_t first = (leaf & ~RT_LEAF_FLAG) >> 4, cnt = leaf & 15u;
     for (uint32_t i = 0; i < cnt; ++i) {
       const DevMeshTri* tp = tris + first + i;
       const uint32_t index = tp->index;
@@ -369,7 +436,9 @@ __device__ __forceinline__ void hit_geometry(const DevScene& sc, const DevObject
 // Scene::intersect_ray (src/scene.rs:135-150): closest over the object list in scene order,
 // strict '<' so the earlier object keeps a tie. The hit point and normal are formed once,
 // for the winner only.
-template <int RULE, bool COUNT>
+// MESH = false: the scene has no model at all, and the traversal code is left out of the kernel (it would cost the
+// analytic-only scenes registers, i.e. spills at four waves per SIMD).
+template <int RULE, bool COUNT, bool MESH = true>
 __device__ __forceinline__ bool closest_hit(const DevScene& sc, const uint4* __restrict__ node_words, V3 o, V3 d,
                                             uint32_t* stack, Hit& hit, uint32_t& n_nodes, uint32_t& n_prims) {
   bool found = false;
@@ -388,10 +457,19 @@ __device__ __forceinline__ bool closest_hit(const DevScene& sc, const uint4* __r
     } else if (ob.kind == RT_OBJ_TRIANGLE) {
       const DevTopTri& tr = sc.top_tris[ob.first];
       ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, tr.frame.len, t_raw, t);
+    } else if (!MESH) {
+      continue;
     } else {
       MeshHit mh;
-      ok = mesh_closest<RULE, COUNT>(node_words + size_t(ob.root) * 4, sc.mesh_tris + ob.first, sc.mesh_frames + ob.first, ob, o, d, dn, stack, mh,
-                                     n_nodes, n_prims);
+      const DevMeshTri* tris = sc.mesh_tris + ob.first;
+      const DevTriFrame* frames = sc.mesh_frames + ob.first;
+      // the format is the same for every lane (a property of the scene); the nearest-only form never meets the first-index rule
+      if (sc.node_format == RT_NODES_SMALL)
+        ok = mesh_closest<RT_NODES_SMALL, RULE, COUNT>(node_words + size_t(ob.root) * 2, tris, frames, ob, o, d, dn, stack, mh, n_nodes, n_prims);
+      else if (RULE == RT_HIT_NEAREST && sc.node_format == RT_NODES_NEAREST)
+        ok = mesh_closest<RT_NODES_NEAREST, RULE, COUNT>(node_words + size_t(ob.root) * 2, tris, frames, ob, o, d, dn, stack, mh, n_nodes, n_prims);
+      else
+        ok = mesh_closest<RT_NODES_WIDE, RULE, COUNT>(node_words + size_t(ob.root) * 3, tris, frames, ob, o, d, dn, stack, mh, n_nodes, n_prims);
       t = mh.t; t_raw = mh.t_raw; prim = mh.index; slot = mh.slot;
     }
     if (ok && (!found || t < best_t)) {
@@ -609,7 +687,7 @@ __device__ __forceinline__ bool local_pixel_to_xy(const BatchDesc& b, uint32_t l
 // an LDS read instead of an L2 round trip, which is what a long first-index traversal waits on.
 template <bool STAGED>
 __device__ __forceinline__ const uint4* stage_nodes(const DevScene& sc, uint4* lds, uint32_t*& stack) {
-  const uint32_t words = STAGED ? sc.lds_nodes * 4 : 0;
+  const uint32_t words = STAGED ? sc.lds_nodes : 0;
   stack = reinterpret_cast<uint32_t*>(lds + words) + threadIdx.x;
   const uint4* src = reinterpret_cast<const uint4*>(sc.nodes);
   if (!STAGED) return src;
@@ -946,7 +1024,7 @@ typedef const __attribute__((address_space(4))) BounceArgs* BounceArgsPtr;
 // its state comes from `in`. Used for scenes without meshes, where every lane does the same work.
 // Held to 128 registers (four waves per SIMD): the standard materials need a few more than that, the extension
 // materials about 40 more, and the spilled values cost less than the fourth wave brings (measured +9 % and +6 %).
-template <bool PRIMARY, int RULE, bool COUNT, bool EXT>
+template <bool PRIMARY, int RULE, bool COUNT, bool EXT, bool MESH = true>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
 bounce_kernel(BounceArgs a) {
   const BounceArgsPtr ap = (BounceArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -986,7 +1064,7 @@ bounce_kernel(BounceArgs a) {
     sh.alive = false; sh.emits = false; sh.emit_info = 0; sh.no = ps.o; sh.nd = ps.d;
     if (active) {
       Hit hit;
-      const bool found = closest_hit<RULE, COUNT>(sc, node_words, ps.o, ps.d, stack, hit, n_nodes, n_prims);
+      const bool found = closest_hit<RULE, COUNT, MESH>(sc, node_words, ps.o, ps.d, stack, hit, n_nodes, n_prims);
       sh = shade_hit<EXT>(sc, b, o, found, hit, PRIMARY, ps);
     }
     append_emit(sc, o, chunk, deep, sh.emits, sh.emit_info, ps.slot, ps.chain);
@@ -1204,10 +1282,11 @@ constexpr uint32_t kMinWaveShare = RT_MIN_WAVE_SHARE;   // entries; a smaller sh
 #endif
 constexpr uint32_t kMaxRounds = RT_MAX_ROUNDS;
 
-template <int RULE, bool COUNT, bool STAGED>
+template <int FMT, int RULE, bool COUNT, bool STAGED>
 __global__ void __launch_bounds__(kBlock)
 traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries, FixedOrigin origin, uint32_t resident_waves,
                 TraversalCounters* counters) {
+  typedef NodeFmt<FMT> F;
   extern __shared__ uint4 lds_dynamic[];
   __shared__ uint32_t s_prefix[kShards + 1];   // list entries before each region
   uint32_t* stack;
@@ -1237,13 +1316,13 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
   uint32_t next = begin < total ? uint32_t(begin) : total;
   const uint32_t end = begin + share < total ? uint32_t(begin + share) : total;
 
-  constexpr uint32_t kDone = RT_REF_NONE;  // has the leaf bit set, so it also ends the node loop
+  constexpr uint32_t kDone = F::kNone;     // has the leaf bit set, so it also ends the node loop
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t n_nodes = 0, n_prims = 0;
   uint32_t w_nodes = 0, w_prims = 0, w_service = 0, n_service = 0;   // COUNT only: wave-level iterations per phase
   uint32_t entry = RT_MISS;                // queue entry whose ray this lane is working on
   V3 o = mk(0, 0, 0), dn = mk(1, 0, 0);
-  BoxRay br = {};
+  QuantRay qr = {};
   uint32_t m = 0;                          // which mesh of the scene the lane is in
   uint32_t root = 0, first_tri = 0;
   MeshHit mh;                              // best inside the current mesh
@@ -1292,7 +1371,8 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
     }
     if (cur == kDone && lf == kNoLeaf && entry != RT_MISS) {   // enter mesh m
       const DevObject& ob = sc.objects[sc.mesh_objects[m]];
-      br = make_box_ray(o, dn, ob);
+      const BoxRay br = make_box_ray(o, dn, ob);
+      qr = make_quant_ray(br, ob);
       root = ob.root; first_tri = ob.first;
       mh.t = INFINITY; mh.t_raw = 0.0; mh.index = RT_MISS; mh.slot = 0;
       cur = 0; sp = 0;
@@ -1312,11 +1392,11 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
     // touched left the node step at 27 % lane occupancy and the triangle step at 40 %.) `lf` counts itself down: after
     // each tested triangle its first-triangle field goes up and its count field down.
     for (;;) {
-      if ((cur & RT_LEAF_FLAG) && cur != kDone && lf == kNoLeaf) {   // park the leaf, keep walking
-        lf = cur;
+      if ((cur & F::kLeaf) && cur != kDone && lf == kNoLeaf) {   // park the leaf, keep walking
+        lf = F::leaf(cur);
         cur = sp ? stack[(--sp) * kBlock] : kDone;
       }
-      const bool walking = !(cur & RT_LEAF_FLAG);
+      const bool walking = !(cur & F::kLeaf);
       const bool has_leaf = lf != kNoLeaf;
       const uint32_t n_walking = uint32_t(__popcll(__ballot(walking))), n_leaf = uint32_t(__popcll(__ballot(has_leaf)));
       if (n_walking + n_leaf == 0) break;
@@ -1326,18 +1406,12 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
       if (n_walking >= n_leaf) {
         if (walking) {
           if (COUNT) count_slot(w_nodes);
-          const uint4* np = node_words + (size_t(root) + cur) * 4;
-          const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
           if (COUNT) ++n_nodes;
-          const float lo0[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
-          const float hi0[3] = {__uint_as_float(w0.w), __uint_as_float(w1.x), __uint_as_float(w1.y)};
-          const float lo1[3] = {__uint_as_float(w1.z), __uint_as_float(w1.w), __uint_as_float(w2.x)};
-          const float hi1[3] = {__uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w)};
-          const uint32_t ref0 = w3.x, ref1 = w3.y, min0 = w3.z, min1 = w3.w;
           const float tmax = RULE == RT_HIT_NEAREST ? __double2float_ru(mh.t) * 1.000002f : INFINITY;
-          float tn0, tn1;
-          bool h0 = slab32(lo0, hi0, br, tmax, tn0) & (ref0 != RT_REF_NONE);   // no branch: empty slots are rare
-          bool h1 = slab32(lo1, hi1, br, tmax, tn1) & (ref1 != RT_REF_NONE);
+          const Children c = test_children<FMT>(node_words + (size_t(root) + cur) * F::kWords4, qr, tmax);
+          const uint32_t ref0 = c.ref0, ref1 = c.ref1, min0 = c.min0, min1 = c.min1;
+          const float tn0 = c.tn0, tn1 = c.tn1;
+          bool h0 = c.h0, h1 = c.h1;
           if (RULE == RT_HIT_FIRST_INDEX) { h0 = h0 && min0 < mh.index; h1 = h1 && min1 < mh.index; }
           if (h0 && h1) {
             const bool swap = RULE == RT_HIT_FIRST_INDEX ? (min1 < min0) : (tn1 < tn0);
@@ -1516,7 +1590,7 @@ inline uint32_t grid_for(size_t n) {
 }
 
 inline size_t stack_bytes(const DevScene& sc) {
-  return size_t(sc.lds_nodes) * sizeof(BvhNode) + size_t(sc.stack_entries) * kBlock * sizeof(uint32_t);
+  return size_t(sc.lds_nodes) * sizeof(uint4) + size_t(sc.stack_entries) * kBlock * sizeof(uint32_t);
 }
 
 }  // namespace
@@ -1525,6 +1599,11 @@ inline size_t stack_bytes(const DevScene& sc) {
 // for, and whether the scene has extension materials (the fused kernel reads BVH nodes from memory, never LDS)
 #define RTMI_DISPATCH(KERNEL, PRIM, ...)                                                                    \
   do {                                                                                                      \
+    if (sc.n_meshes == 0) {   /* no traversal code, no hit rule, nothing to count */                        \
+      if (sc.extension_materials) hipLaunchKernelGGL((KERNEL<PRIM, 0, false, true, false>), grid, kBlock, lds, s, __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<PRIM, 0, false, false, false>), grid, kBlock, lds, s, __VA_ARGS__);   \
+      break;                                                                                                \
+    }                                                                                                       \
     const int sel_ = (sc.hit_rule == RT_HIT_NEAREST ? 4 : 0) | (counters ? 2 : 0) | (sc.extension_materials ? 1 : 0); \
     switch (sel_) {                                                                                         \
       case 0: hipLaunchKernelGGL((KERNEL<PRIM, 0, false, false>), grid, kBlock, lds, s, __VA_ARGS__); break; \
@@ -1590,17 +1669,22 @@ void launch_traverse(const DevScene& sc, PathQueue q, MeshList mesh, uint32_t ma
   const uint32_t resident = 256u * std::max(1u, blocks_per_cu) * (kBlock / 64);
   const size_t waves = std::min<size_t>((size_t(max_in) + kMinWaveShare - 1) / kMinWaveShare, size_t(resident) * kMaxRounds);
   const dim3 grid(uint32_t(std::max<size_t>(1, (std::max<size_t>(waves, resident) + kBlock / 64 - 1) / (kBlock / 64))));
-  const int sel = (sc.hit_rule == RT_HIT_NEAREST ? 4 : 0) | (counters ? 2 : 0) | (sc.lds_nodes ? 1 : 0);
-  switch (sel) {
-    case 0: hipLaunchKernelGGL((traverse_kernel<0, false, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;
-    case 1: hipLaunchKernelGGL((traverse_kernel<0, false, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;
-    case 2: hipLaunchKernelGGL((traverse_kernel<0, true, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;
-    case 3: hipLaunchKernelGGL((traverse_kernel<0, true, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;
-    case 4: hipLaunchKernelGGL((traverse_kernel<1, false, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;
-    case 5: hipLaunchKernelGGL((traverse_kernel<1, false, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;
-    case 6: hipLaunchKernelGGL((traverse_kernel<1, true, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;
-    default: hipLaunchKernelGGL((traverse_kernel<1, true, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;
-  }
+  // node format x hit rule (the nearest-only format never meets the first-index rule) x counters x staged nodes
+#define RTMI_TRAVERSE(FMT, RULE)                                                                                                   \
+  do {                                                                                                                             \
+    const int sel_ = (counters ? 2 : 0) | (sc.lds_nodes ? 1 : 0);                                                                  \
+    switch (sel_) {                                                                                                                \
+      case 0: hipLaunchKernelGGL((traverse_kernel<FMT, RULE, false, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break; \
+      case 1: hipLaunchKernelGGL((traverse_kernel<FMT, RULE, false, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;  \
+      case 2: hipLaunchKernelGGL((traverse_kernel<FMT, RULE, true, false>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;  \
+      default: hipLaunchKernelGGL((traverse_kernel<FMT, RULE, true, true>), grid, kBlock, lds, s, sc, q, mesh, region_entries, origin, resident, counters); break;  \
+    }                                                                                                                              \
+  } while (0)
+  const bool nearest = sc.hit_rule == RT_HIT_NEAREST;
+  if (sc.node_format == RT_NODES_SMALL) { if (nearest) RTMI_TRAVERSE(RT_NODES_SMALL, 1); else RTMI_TRAVERSE(RT_NODES_SMALL, 0); }
+  else if (nearest) RTMI_TRAVERSE(RT_NODES_NEAREST, 1);
+  else RTMI_TRAVERSE(RT_NODES_WIDE, 0);
+#undef RTMI_TRAVERSE
 }
 
 void launch_intersect(const DevScene& sc, const void* rays_, size_t n, void* hits_, TraversalCounters* counters, hipStream_t s) {

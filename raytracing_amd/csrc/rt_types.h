@@ -47,8 +47,12 @@ struct DevObject {
   float inner_hi[3];
   double gate_lo[3];
   double gate_hi[3];
+  // Models only: the grid the node boxes are quantised on, relative to center: plane = grid_lo + q * grid_step
+  float grid_lo[3];
+  float grid_step[3];
+  uint32_t pad2[2];
 };
-static_assert(sizeof(DevObject) == 160, "DevObject must be 160 bytes");
+static_assert(sizeof(DevObject) == 192, "DevObject must be 192 bytes");
 
 struct DevSphere {
   double l2w[12];
@@ -74,6 +78,7 @@ struct DevTopTri {
 // Child reference: RT_LEAF_FLAG | first << 4 | count for a leaf (first is relative to the
 // model's first mesh triangle), a node index (relative to the model's root) otherwise,
 // RT_REF_NONE for an empty slot. min_index = smallest file-order triangle index below the child.
+// This is the builder's working form; the device walks the quantised form below.
 struct BvhNode {
   float lo0[3], hi0[3];
   float lo1[3], hi1[3];
@@ -81,6 +86,23 @@ struct BvhNode {
   uint32_t min_index0, min_index1;
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+// What the kernels traverse: both children's boxes as 16-bit coordinates on a per-mesh grid (DevObject::grid_lo,
+// grid_step), rounded outward by a further grid step, so a quantised box always contains the binary32 box it came
+// from. A box test fetches 24 bytes of planes instead of 48, and a node 32 or 48 bytes instead of 64: the traversal is
+// bound by the vector memory path (address and data-return units busy 75-90 % of its time), not by arithmetic.
+//   words 0-5  lo0.x|lo0.y<<16, lo0.z|hi0.x<<16, hi0.y|hi0.z<<16, lo1.x|lo1.y<<16, lo1.z|hi1.x<<16, hi1.y|hi1.z<<16
+//   RT_NODES_SMALL   (32 bytes; every mesh of the scene has at most RT_SMALL_MAX_TRIS triangles)
+//              word 6 = ref0 | ref1 << 16, word 7 = min_index0 | min_index1 << 16, with 16-bit references:
+//              0xFFFF none, 0x8000 | first << 2 | (count - 1) a leaf of 1..4 triangles, else a node index
+//   RT_NODES_NEAREST (32 bytes; nearest-hit rule only, which never reads the minimum indices)
+//              word 6 = ref0, word 7 = ref1, as in BvhNode
+//   RT_NODES_WIDE    (48 bytes) words 6-9 = ref0, ref1, min_index0, min_index1, as in BvhNode; words 10-11 unused
+struct alignas(16) RtWord4 { uint32_t x, y, z, w; };
+enum { RT_NODES_SMALL = 0, RT_NODES_NEAREST = 1, RT_NODES_WIDE = 2 };
+#define RT_SMALL_MAX_TRIS 8188u
+#define RT_SMALL_LEAF_FLAG 0x8000u
+#define RT_SMALL_REF_NONE 0xFFFFu
 
 struct DevMeshTri {
   double v[9];
@@ -102,7 +124,7 @@ struct DevScene {
   const DevObject* objects;
   const DevSphere* spheres;
   const DevTopTri* top_tris;
-  const BvhNode* nodes;
+  const RtWord4* nodes;        // quantised nodes of every mesh, 2 or 3 x 16 bytes each (node_format)
   const DevMeshTri* mesh_tris;
   const DevTriFrame* mesh_frames;   // parallel to mesh_tris
   const DevMaterial* materials;
@@ -113,7 +135,8 @@ struct DevScene {
   uint32_t hit_rule;
   uint32_t stack_entries;     // LDS traversal stack depth per lane
   uint32_t n_spectra;
-  uint32_t lds_nodes;         // > 0: all BVH nodes of the scene (this many) are staged into LDS by every workgroup
+  uint32_t lds_nodes;         // > 0: all BVH nodes of the scene (this many 16-byte words) are staged into LDS by every workgroup
+  uint32_t node_format;       // RT_NODES_*
   uint32_t extension_materials;  // some material is glossy or dielectric: kernels with that shading code are used
 };
 

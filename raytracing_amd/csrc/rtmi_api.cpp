@@ -567,7 +567,9 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   std::vector<DevObject> objects(d->n_objects);
   std::vector<DevSphere> spheres;
   std::vector<DevTopTri> top_tris;
-  std::vector<BvhNode> nodes;
+  std::vector<BvhBuild> builds;      // one per model, in mesh_objects order (their triangles moved out)
+  std::vector<RtWord4> nodes;        // the quantised nodes of every model
+  uint32_t n_nodes = 0, largest_mesh = 0, largest_leaf = 0;
   std::vector<DevMeshTri> mesh_tris;
   std::vector<DevTriFrame> mesh_frames;
   std::vector<uint32_t> mesh_objects;
@@ -619,9 +621,11 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
       if (uint64_t(o.first) + o.count > d->n_triangles) return fail(RTMI_BAD_ARG, "object %u: triangles [%u,+%u) out of range", i, o.first, o.count);
       if (o.count >= (1u << 27)) return fail(RTMI_UNSUPPORTED, "object %u: %u triangles in one mesh", i, o.count);
       Timer bvh_timer;
-      BvhBuild bb = build_bvh(o.count ? d->triangles[o.first].v : nullptr, o.count, 4);
+      constexpr uint32_t leaf_size = 4;   // the 16-bit leaf references of RT_NODES_SMALL count up to 4
+      BvhBuild bb = build_bvh(o.count ? d->triangles[o.first].v : nullptr, o.count, leaf_size);
+      largest_leaf = std::max(largest_leaf, leaf_size);
       bvh_build_ms += bvh_timer.ms();
-      dobj.root = uint32_t(nodes.size());
+      dobj.root = n_nodes;          // in nodes; the quantised words are laid out once the scene's node format is known
       dobj.first = uint32_t(mesh_tris.size());
       std::memcpy(dobj.center, bb.center, sizeof dobj.center);
       dobj.radius = bb.radius;
@@ -632,23 +636,38 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
       }
       set_model_gate(dobj, o.count ? d->triangles[o.first].v : nullptr, o.count, bb.radius);
       mesh_objects.push_back(i);
-      nodes.insert(nodes.end(), bb.nodes.begin(), bb.nodes.end());
+      n_nodes += uint32_t(bb.nodes.size());
+      largest_mesh = std::max(largest_mesh, o.count);
       mesh_tris.insert(mesh_tris.end(), bb.tris.begin(), bb.tris.end());
       for (const DevMeshTri& t : bb.tris) mesh_frames.push_back(tri_frame(t.v));
       max_depth = std::max(max_depth, bb.max_depth);
+      bb.tris.clear(); bb.tris.shrink_to_fit();
+      builds.push_back(std::move(bb));
     } else {
       return fail(RTMI_UNSUPPORTED, "object %u has unknown kind %u", i, o.kind);
     }
     objects[i] = dobj;
   }
-  const uint32_t stack_entries = nodes.empty() ? 0 : max_depth + 1;
+  // One node format per scene (the kernels are instantiated per format): the 32-byte form with 16-bit references when
+  // every mesh is small enough, else 32 bytes without minimum indices under the nearest rule, else 48 bytes.
+  const int node_format = largest_mesh <= RT_SMALL_MAX_TRIS && largest_leaf <= 4 ? RT_NODES_SMALL
+                        : d->hit_rule == RTMI_HIT_NEAREST ? RT_NODES_NEAREST : RT_NODES_WIDE;
+  {
+    Timer quant_timer;
+    for (size_t m = 0; m < builds.size(); ++m) {
+      const QuantizedNodes q = quantize_nodes(builds[m], node_format);
+      DevObject& ob = objects[mesh_objects[m]];
+      for (int k = 0; k < 3; ++k) { ob.grid_lo[k] = q.grid_lo[k]; ob.grid_step[k] = q.grid_step[k]; }
+      nodes.insert(nodes.end(), q.words.begin(), q.words.end());
+      builds[m] = BvhBuild{};
+    }
+    bvh_build_ms += quant_timer.ms();
+  }
+  const uint32_t stack_entries = n_nodes == 0 ? 0 : max_depth + 1;
   const size_t stack_lds = size_t(stack_entries) * kBlock * sizeof(uint32_t);
   if (stack_lds > 150 * 1024) return fail(RTMI_UNSUPPORTED, "BVH depth %u needs more LDS than a CU has", max_depth);
-  // Stage the whole tree into LDS only while three workgroups (nodes + stacks each) still fit in a
-  // CU's 160 KB: the kernels are bound by binary64 VALU issue, not by node-fetch latency, so giving
-  // up a resident wave per SIMD for LDS space costs more than the faster fetch returns (measured on
-  // the 613-node Suzanne tree: 2 workgroups/CU with staged nodes ran 8 % slower than 3 without).
-  const size_t node_bytes = nodes.size() * sizeof(BvhNode);
+  // Stage the whole tree into LDS only while three workgroups (nodes + stacks each) still fit in a CU's 160 KB.
+  const size_t node_bytes = nodes.size() * sizeof(RtWord4);
   const bool stage = !nodes.empty() && 3 * (node_bytes + stack_lds) + 3 * 1024 <= 160 * 1024 && !getenv("RTMI_NO_LDS_NODES");
 
   std::unique_ptr<rtmi_scene> s(new rtmi_scene);
@@ -662,7 +681,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
     return rc;
   }
   s->dev.objects = s->objects.as<DevObject>(); s->dev.spheres = s->spheres.as<DevSphere>();
-  s->dev.top_tris = s->top_tris.as<DevTopTri>(); s->dev.nodes = s->nodes.as<BvhNode>();
+  s->dev.top_tris = s->top_tris.as<DevTopTri>(); s->dev.nodes = s->nodes.as<RtWord4>();
   s->dev.mesh_tris = s->mesh_tris.as<DevMeshTri>(); s->dev.mesh_frames = s->mesh_frames.as<DevTriFrame>();
   s->dev.materials = s->materials.as<DevMaterial>();
   s->dev.spectra = s->spectra.as<float>();
@@ -672,9 +691,10 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   s->dev.n_objects = d->n_objects; s->dev.hit_rule = d->hit_rule; s->dev.stack_entries = stack_entries;
   s->dev.n_spectra = uint32_t(spectra.size() / RT_NBINS);
   s->dev.lds_nodes = stage ? uint32_t(nodes.size()) : 0;
-  s->info.n_nodes = uint32_t(nodes.size()); s->info.max_depth = max_depth;
+  s->dev.node_format = uint32_t(node_format);
+  s->info.n_nodes = n_nodes; s->info.max_depth = max_depth;
   s->info.n_mesh_triangles = uint32_t(mesh_tris.size()); s->info.n_spectra = s->dev.n_spectra;
-  s->info.node_bytes = nodes.size() * sizeof(BvhNode); s->info.triangle_bytes = mesh_tris.size() * (sizeof(DevMeshTri) + sizeof(DevTriFrame));
+  s->info.node_bytes = nodes.size() * sizeof(RtWord4); s->info.triangle_bytes = mesh_tris.size() * (sizeof(DevMeshTri) + sizeof(DevTriFrame));
   s->info.bvh_build_ms = bvh_build_ms; s->info.upload_ms = create_timer.ms() - bvh_build_ms;
   *out = s.release();
   return RTMI_OK;
