@@ -12,7 +12,7 @@
  *    message of the calling thread's last failure; nothing aborts or throws across the ABI;
  *  - the caller owns every input array (copied during the call) and every output buffer;
  *  - a context is bound to one GPU; one call at a time per context; distinct contexts may be
- *    used from different threads or processes (one process per GPU is the intended model);
+ *    used from different threads or processes (one process per GPU, or rtmi_multi_* inside one process);
  *  - "host" pointers are ordinary memory, "device" pointers are HIP device memory of the
  *    context's GPU; `stream` is a hipStream_t passed as void* (NULL = the default stream);
  *  - images are row-major with y = 0 at the top (src/camera.rs:26-29).
@@ -222,6 +222,34 @@ int rtmi_render_collect_stats(rtmi_scene* scene, void* stream, rtmi_stats* stats
 /* mean = sum / spp, XYZ -> RGB, clamp, gamma, u8 (src/integrators/integrator.rs:79-90). */
 int rtmi_tonemap(rtmi_ctx* ctx, const float* dev_xyz_sum, uint32_t spp, uint32_t width, uint32_t height,
                  uint8_t* dev_rgb8, void* stream);
+
+/* ---- one render over several GPUs of a node: what replaces the tile thread pool (src/parallel.rs:37-61) and the
+ *      render loop that feeds it (src/integrators/integrator.rs:30-118) when more than one device is used.
+ *      The scene is replicated on every device, each device renders its share on its own host thread and stream, and
+ *      ONE collective merges the per-pixel XYZ sums (W*H*3 floats) on the first device: an RCCL reduce over xGMI.
+ *        RTMI_PARTITION_SAMPLES  device r renders samples [r*spp/n, (r+1)*spp/n) of every pixel with the same Philox
+ *                                key; perfectly balanced; differs from one device only by float summation order
+ *        RTMI_PARTITION_TILES    device r renders the tiles k (x-major, src/integrators/integrator.rs:50) with
+ *                                k % n == r; the buffers are disjoint, so the image is bit-identical to one device's
+ *      device_ids may repeat (more shares than GPUs); shares that live on the same GPU cannot form an RCCL
+ *      communicator, so the merge is then done with copies to the first device and adds. RCCL is bound at run time
+ *      (a librccl already in the process, RTMI_RCCL_LIB, the directory of the loaded HIP runtime, the loader path). */
+enum { RTMI_PARTITION_SAMPLES = 0, RTMI_PARTITION_TILES = 1 };
+typedef struct rtmi_multi rtmi_multi;
+typedef struct {
+  uint32_t n_ranks;
+  uint32_t uses_rccl;        /* 1: the merge is an ncclReduce; 0: one rank, or copies and adds */
+  char rccl_library[240];    /* the library the RCCL entry points were taken from */
+} rtmi_multi_info_t;
+/* Contexts and scene replicas on device_ids[0..n); max_batch_paths as in rtmi_ctx_create, per device. */
+int rtmi_multi_create(const int* device_ids, int n, uint64_t max_batch_paths, const rtmi_scene_desc* desc, rtmi_multi** out);
+void rtmi_multi_destroy(rtmi_multi* multi);
+int rtmi_multi_info(const rtmi_multi* multi, rtmi_multi_info_t* out);
+/* SamplerIntegrator::render over all devices of the handle. The partition fields of `params` (sample_begin/end,
+ * tile_rank/world) must be 0. Outputs as in rtmi_render. stats: totals over the devices (ms_total = wall time of the
+ * call); per_rank_stats (optional): n entries, one per device. Blocks until the image is on the host. */
+int rtmi_multi_render(rtmi_multi* multi, const rtmi_camera* cam, const rtmi_render_params* params, uint32_t partition,
+                      uint8_t* host_rgb8, float* host_xyz, rtmi_stats* stats, rtmi_stats* per_rank_stats);
 
 #ifdef __cplusplus
 }

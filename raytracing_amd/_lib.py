@@ -26,6 +26,7 @@ HIT_FIRST_INDEX, HIT_NEAREST = 0, 1
 INT_RANDOM_WALK, INT_ALBEDO, INT_NORMAL = 0, 1, 2
 SPEC_REFLECTANCE, SPEC_ILLUMINANT = 0, 1
 FLAG_TIME_KERNELS, FLAG_COUNT_TRAVERSAL = 1, 2
+PARTITION_SAMPLES, PARTITION_TILES = 0, 1
 
 # numpy record layouts of the plain C structs
 RAY_DT = np.dtype([("o", "<f8", 3), ("d", "<f8", 3)])
@@ -67,6 +68,10 @@ class Stats(C.Structure):
                 ("mesh_rays", C.c_uint64), ("ms_traverse", C.c_double), ("traverse_launches", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class MultiInfo(C.Structure):
+    _fields_ = [("n_ranks", C.c_uint32), ("uses_rccl", C.c_uint32), ("rccl_library", C.c_char * 240)]
+
+
 class SceneInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("max_depth", C.c_uint32), ("n_mesh_triangles", C.c_uint32), ("n_spectra", C.c_uint32),
                 ("node_bytes", C.c_uint64), ("triangle_bytes", C.c_uint64), ("bvh_build_ms", C.c_double), ("upload_ms", C.c_double)]
@@ -98,6 +103,11 @@ SYMBOLS = {
                                          C.POINTER(Stats)]),
     "rtmi_render_accumulate_noalloc": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p]),
     "rtmi_render_collect_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
+    "rtmi_multi_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_uint64, C.POINTER(SceneDesc), C.POINTER(C.c_void_p)]),
+    "rtmi_multi_destroy": (None, [C.c_void_p]),
+    "rtmi_multi_info": (C.c_int, [C.c_void_p, C.POINTER(MultiInfo)]),
+    "rtmi_multi_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_uint32, C.c_void_p, C.c_void_p,
+                                    C.POINTER(Stats), C.POINTER(Stats)]),
     "rtmi_tonemap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
 }
 

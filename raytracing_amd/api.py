@@ -160,3 +160,46 @@ class Scene:
         st = L.Stats()
         L.check(L.lib().rtmi_render_collect_stats(self.handle, C.c_void_p(stream), C.byref(st)))
         return stats_dict(st)
+
+
+class MultiScene:
+    """A scene replicated over several GPUs of this process (rtmi_multi_create): one render is partitioned over them
+    and merged with one collective."""
+
+    def __init__(self, device_ids, objects, spheres, triangles, materials, hit_rule=L.HIT_FIRST_INDEX, max_batch_paths=0):
+        objects = np.ascontiguousarray(objects, dtype=L.OBJECT_DT)
+        spheres = np.ascontiguousarray(spheres, dtype=L.SPHERE_DT)
+        triangles = np.ascontiguousarray(triangles, dtype=L.TRIANGLE_DT)
+        materials = np.ascontiguousarray(materials, dtype=L.MATERIAL_DT)
+        d = L.SceneDesc(objects.ctypes.data, len(objects), spheres.ctypes.data, len(spheres), triangles.ctypes.data,
+                        len(triangles), materials.ctypes.data, len(materials), int(hit_rule), 0)
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        L.check(L.lib().rtmi_multi_create(ids, len(device_ids), int(max_batch_paths), C.byref(d), C.byref(h)))
+        self.handle, self.n = h, len(device_ids)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            L.lib().rtmi_multi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        i = L.MultiInfo()
+        L.check(L.lib().rtmi_multi_info(self.handle, C.byref(i)))
+        return {"n_ranks": i.n_ranks, "uses_rccl": bool(i.uses_rccl), "rccl_library": i.rccl_library.decode()}
+
+    def render(self, cam, params, partition=L.PARTITION_SAMPLES, want_xyz=True):
+        w, h = cam.width, cam.height
+        rgb8 = np.zeros((h, w, 3), dtype=np.uint8)
+        xyz = np.zeros((h, w, 3), dtype=np.float32) if want_xyz else None
+        st = L.Stats()
+        per = (L.Stats * self.n)()
+        L.check(L.lib().rtmi_multi_render(self.handle, C.byref(cam), C.byref(params), int(partition), rgb8.ctypes.data,
+                                          xyz.ctypes.data if want_xyz else None, C.byref(st), per))
+        return rgb8, xyz, stats_dict(st), [stats_dict(p) for p in per]

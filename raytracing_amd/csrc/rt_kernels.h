@@ -180,6 +180,8 @@ void launch_sum_counts(const uint32_t* counts, uint32_t n_levels, unsigned long 
 // (level k and level pair_level0 + k, k < n_pairs) together hold more than region_entries paths
 void launch_check_overflow(const uint32_t* counts, uint32_t n_levels, uint32_t pair_level0, uint32_t n_pairs,
                            uint32_t region_entries, uint32_t* flag, hipStream_t s);
+// dst[i] += src[i]
+void launch_add(float* dst, const float* src, size_t n, hipStream_t s);
 void launch_tonemap(const float* xyz_sum, uint32_t spp, uint32_t n_pixels, uint8_t* rgb8, hipStream_t s);
 
 }  // namespace rtmi

@@ -1548,6 +1548,10 @@ __global__ void __launch_bounds__(kBlock) fill_tiles_kernel(uint32_t* __restrict
   if (j < n) tiles[j] = first + j * stride;
 }
 
+__global__ void __launch_bounds__(kBlock) add_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+  for (size_t i = size_t(blockIdx.x) * kBlock + threadIdx.x; i < n; i += size_t(gridDim.x) * kBlock) dst[i] = dst[i] + src[i];
+}
+
 // One wave: lane r looks at region r of every level.
 __global__ void check_overflow_kernel(const uint32_t* counts, uint32_t n_levels, uint32_t pair_level0, uint32_t n_pairs,
                                       uint32_t region_entries, uint32_t* flag) {
@@ -1724,6 +1728,11 @@ void launch_sum_counts(const uint32_t* counts, uint32_t n_levels, unsigned long 
 void launch_fill_tiles(uint32_t* tiles, uint32_t n, uint32_t first, uint32_t stride, hipStream_t s) {
   if (n == 0) return;
   hipLaunchKernelGGL(fill_tiles_kernel, dim3((n + kBlock - 1) / kBlock), kBlock, 0, s, tiles, n, first, stride);
+}
+
+void launch_add(float* dst, const float* src, size_t n, hipStream_t s) {
+  if (n == 0) return;
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), kBlock, 0, s, dst, src, n);
 }
 
 void launch_check_overflow(const uint32_t* counts, uint32_t n_levels, uint32_t pair_level0, uint32_t n_pairs,

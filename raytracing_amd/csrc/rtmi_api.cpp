@@ -40,6 +40,15 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+}  // namespace
+
+namespace rtmi {
+// for the other translation units of the library: sets the calling thread's rtmi_last_error() and returns `code`
+int set_last_error(int code, const char* message) { g_error = message; return code; }
+}
+
+namespace {
+
 #define HIP_TRY(expr)                                                                              \
   do {                                                                                             \
     hipError_t e_ = (expr);                                                                        \

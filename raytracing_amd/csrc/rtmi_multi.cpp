@@ -248,9 +248,8 @@ extern "C" int rtmi_multi_render(rtmi_multi* m, const rtmi_camera* cam, const rt
       const uint32_t begin = uint32_t(i) * base + std::min<uint32_t>(uint32_t(i), extra);
       const uint32_t end = begin + base + (i < extra ? 1u : 0u);
       p.sample_begin = begin; p.sample_end = end;
-      if (end == begin) { p.sample_begin = 0; p.sample_end = 0; p.tile_rank = 0; p.tile_world = 1; p.spp = params->spp; }
-      // a rank with no sample at all (more ranks than samples) still has to clear its buffer: give it an empty tile share
-      if (end == begin) { p.tile_world = 0xFFFFFFFFu; p.tile_rank = 0xFFFFFFFEu; }
+      // more ranks than samples: this rank gets an empty tile share (it still clears its buffer for the merge)
+      if (end == begin) { p.sample_begin = p.sample_end = 0; p.tile_world = 0xFFFFFFFFu; p.tile_rank = 0xFFFFFFFEu; }
     } else {
       p.tile_rank = uint32_t(i); p.tile_world = uint32_t(n);
     }
