@@ -115,23 +115,36 @@ struct Workspace {
   uint32_t* tiles = nullptr;      // tile ids of the current render
 };
 
-struct rtmi_ctx {
-  int device = 0;
-  uint64_t max_batch_paths = 0;
-  // workspace shared by every scene of the context (one call at a time per context)
+constexpr int kMaxLanes = 4;
+
+// A workspace with the buffers it is carved from.
+struct WorkspaceMem {
   Workspace ws;
-  DevBuf queue_mem[2];
-  DevBuf contrib, counts, tiles, stats, rays, hits, spectra_out, image;
-  DevBuf emit_mem, mesh_list;
-  bool batch_is_default = true;   // max_batch_paths was not chosen by the caller: it may shrink if memory is short
-  bool inline_emit = false;       // RTMI_INLINE_EMIT (read once, when the context is created): no emit queue, for A/B measurements
-  unsigned char* scratch = nullptr;  // this device's copy of the static scratch array (rtmi_render_accumulate_noalloc)
-  void release_workspace() {
+  DevBuf queue_mem[2], contrib, counts, stats, emit_mem, mesh_list;
+  void release_queues() {
     for (DevBuf* b : {&queue_mem[0], &queue_mem[1], &contrib, &emit_mem, &mesh_list}) b->release();
     ws.queue_entries = 0; ws.queue_deep = false; ws.emit_paths = 0; ws.emit_deep = false;
     ws.queue[0] = ws.queue[1] = PathQueue{}; ws.emit = EmitQueue{}; ws.emit_region_entries = 0;
     ws.mesh_list = nullptr; ws.contrib = nullptr;
   }
+  void release_all() { release_queues(); counts.release(); stats.release(); ws.counts = nullptr; ws.stats = nullptr; }
+};
+
+struct rtmi_ctx {
+  int device = 0;
+  uint64_t max_batch_paths = 0;
+  // Several workspaces (one call at a time per context): the batches of a render take turns in them, each on an internal
+  // stream of its own, so that the thin tail of one batch's launches -- a handful of long traversals keeping a few
+  // waves busy -- overlaps with the bulk of another batch's. Only the workspaces a render uses are allocated.
+  WorkspaceMem wsm[kMaxLanes];
+  hipStream_t lane[kMaxLanes] = {};
+  hipEvent_t ev_fork = nullptr, ev_done[kMaxLanes] = {}, ev_resolved[kMaxLanes] = {};
+  int n_lanes = 2;                // RTMI_LANES (read once, 1..kMaxLanes); 1 = never overlap batches
+  DevBuf tiles, rays, hits, spectra_out, image;
+  bool batch_is_default = true;   // max_batch_paths was not chosen by the caller: it may shrink if memory is short
+  bool inline_emit = false;       // RTMI_INLINE_EMIT (read once, when the context is created): no emit queue, for A/B measurements
+  unsigned char* scratch = nullptr;  // this device's copy of the static scratch array (rtmi_render_accumulate_noalloc)
+  void release_workspace() { for (auto& w : wsm) w.release_queues(); }
 };
 
 struct rtmi_scene {
@@ -142,7 +155,7 @@ struct rtmi_scene {
   // bookkeeping of the last render_accumulate, completed by rtmi_render_collect_stats
   rtmi_stats pending{};
   bool counting = false;
-  DeviceStats* last_stats = nullptr;   // device counters of the last render_accumulate (the context's or the static scratch's)
+  DeviceStats* last_stats[kMaxLanes] = {};   // device counters of the last render_accumulate (one per workspace it used)
   bool fused_only = false;   // RTMI_PIPELINE=fused: one kernel per bounce even with meshes (for A/B measurements)
 };
 
@@ -189,21 +202,21 @@ EmitQueue carve_emit(void* mem, size_t region_entries, bool deep) {
 
 // slack_chunks: see region_chunks(). A failed allocation leaves the context as release_workspace() would: nothing
 // that a later call could mistake for a usable buffer.
-int ensure_workspace(rtmi_ctx* ctx, size_t paths, size_t slack_chunks, bool deep, bool want_queues) {
-  Workspace& ws = ctx->ws;
+int ensure_workspace(WorkspaceMem& m, size_t paths, size_t slack_chunks, bool deep, bool want_queues) {
+  Workspace& ws = m.ws;
   const size_t entries = queue_entries(paths, slack_chunks);
   if (want_queues && (entries > ws.queue_entries || (deep && !ws.queue_deep))) {
     const size_t e = std::max(entries, ws.queue_entries);
     const bool d = deep || ws.queue_deep;
     ws.queue_entries = 0; ws.queue_deep = false; ws.mesh_list = nullptr;
     ws.queue[0] = ws.queue[1] = PathQueue{};
-    for (DevBuf* b : {&ctx->queue_mem[0], &ctx->queue_mem[1], &ctx->mesh_list}) b->release();
+    for (DevBuf* b : {&m.queue_mem[0], &m.queue_mem[1], &m.mesh_list}) b->release();
     for (int i = 0; i < 2; ++i) {
-      if (int rc = ctx->queue_mem[i].reserve(queue_bytes(e, d))) return rc;
-      ws.queue[i] = carve_queue(ctx->queue_mem[i].p, e, d);
+      if (int rc = m.queue_mem[i].reserve(queue_bytes(e, d))) return rc;
+      ws.queue[i] = carve_queue(m.queue_mem[i].p, e, d);
     }
-    if (int rc = ctx->mesh_list.reserve(e * sizeof(uint32_t))) return rc;
-    ws.mesh_list = ctx->mesh_list.as<uint32_t>();
+    if (int rc = m.mesh_list.reserve(e * sizeof(uint32_t))) return rc;
+    ws.mesh_list = m.mesh_list.as<uint32_t>();
     ws.queue_entries = e; ws.queue_deep = d;
   }
   if (want_queues && (paths > ws.emit_paths || (deep && !ws.emit_deep))) {
@@ -211,21 +224,21 @@ int ensure_workspace(rtmi_ctx* ctx, size_t paths, size_t slack_chunks, bool deep
     const bool d = deep || ws.emit_deep;
     const size_t region = emit_entries_for(p);
     ws.emit_paths = 0; ws.emit_deep = false; ws.emit = EmitQueue{}; ws.emit_region_entries = 0;
-    ctx->emit_mem.release();
-    if (int rc = ctx->emit_mem.reserve(emit_bytes(region, d))) return rc;
-    ws.emit = carve_emit(ctx->emit_mem.p, region, d);
+    m.emit_mem.release();
+    if (int rc = m.emit_mem.reserve(emit_bytes(region, d))) return rc;
+    ws.emit = carve_emit(m.emit_mem.p, region, d);
     ws.emit_region_entries = uint32_t(region); ws.emit_paths = p; ws.emit_deep = d;
   }
   ws.contrib = nullptr;
-  if (int rc = ctx->contrib.reserve(paths * 3 * sizeof(float))) return rc;
-  ws.contrib = ctx->contrib.as<float>();
-  if (int rc = ctx->counts.reserve(kCountBytes)) return rc;
-  ws.counts = ctx->counts.as<uint32_t>();
-  if (!ctx->stats.p) {
-    if (int rc = ctx->stats.reserve(sizeof(DeviceStats))) return rc;
-    HIP_TRY(hipMemset(ctx->stats.p, 0, sizeof(DeviceStats)));
+  if (int rc = m.contrib.reserve(paths * 3 * sizeof(float))) return rc;
+  ws.contrib = m.contrib.as<float>();
+  if (int rc = m.counts.reserve(kCountBytes)) return rc;
+  ws.counts = m.counts.as<uint32_t>();
+  if (!m.stats.p) {
+    if (int rc = m.stats.reserve(sizeof(DeviceStats))) return rc;
+    HIP_TRY(hipMemset(m.stats.p, 0, sizeof(DeviceStats)));
   }
-  ws.stats = ctx->stats.as<DeviceStats>();
+  ws.stats = m.stats.as<DeviceStats>();
   return RTMI_OK;
 }
 
@@ -458,6 +471,13 @@ extern "C" int rtmi_ctx_create(int device_id, uint64_t max_batch_paths, rtmi_ctx
   ctx->inline_emit = getenv("RTMI_INLINE_EMIT") != nullptr;
   HIP_TRY(upload_constants(spectrum_tables()));
   if (int rc = static_scratch_address(&ctx->scratch)) return rc;
+  if (const char* e = getenv("RTMI_LANES")) ctx->n_lanes = std::min(std::max(atoi(e), 1), kMaxLanes);
+  for (int i = 0; i < ctx->n_lanes; ++i) {
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->lane[i], hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_resolved[i], hipEventDisableTiming));
+  }
+  HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   *out = ctx.release();
   return RTMI_OK;
 }
@@ -466,9 +486,12 @@ extern "C" void rtmi_ctx_destroy(rtmi_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
-  for (auto& q : ctx->queue_mem) q.release();
-  for (DevBuf* b : {&ctx->contrib, &ctx->counts, &ctx->tiles, &ctx->stats, &ctx->rays, &ctx->hits, &ctx->spectra_out, &ctx->image, &ctx->emit_mem, &ctx->mesh_list})
-    b->release();
+  for (auto& w : ctx->wsm) w.release_all();
+  for (DevBuf* b : {&ctx->tiles, &ctx->rays, &ctx->hits, &ctx->spectra_out, &ctx->image}) b->release();
+  for (hipStream_t st : ctx->lane) if (st) (void)hipStreamDestroy(st);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  for (hipEvent_t e : ctx->ev_done) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->ev_resolved) if (e) (void)hipEventDestroy(e);
   delete ctx;
 }
 
@@ -741,8 +764,8 @@ extern "C" int rtmi_intersect_batch(rtmi_scene* s, const rtmi_ray* rays, size_t 
   const size_t chunk = std::min<size_t>(std::max<size_t>(n, 1), size_t(1) << 24);
   if (int rc = ctx->rays.reserve(chunk * sizeof(rtmi_ray))) return rc;
   if (int rc = ctx->hits.reserve(chunk * sizeof(rtmi_hit))) return rc;
-  if (int rc = ensure_workspace(ctx, 1, 0, false, false)) return rc;
-  DeviceStats* ds = ctx->ws.stats;
+  if (int rc = ensure_workspace(ctx->wsm[0], 1, 0, false, false)) return rc;
+  DeviceStats* ds = ctx->wsm[0].ws.stats;
   const bool count = stats != nullptr;
   if (count) HIP_TRY(hipMemset(ds, 0, sizeof *ds));
   for (size_t at = 0; at < n; at += chunk) {
@@ -780,12 +803,14 @@ extern "C" int rtmi_trace_batch(rtmi_scene* s, const rtmi_ray* rays, size_t n, u
   Timer timer;
   const size_t chunk = std::min<size_t>(std::max<size_t>(n, 1), std::min<uint64_t>(ctx->max_batch_paths, 1u << 22));
   const bool deep = max_depth > 16;
-  if (int rc = ensure_workspace(ctx, chunk, 0, deep, true)) return rc;
+  if (int rc = ensure_workspace(ctx->wsm[0], chunk, 0, deep, true)) return rc;
   if (int rc = ctx->rays.reserve(chunk * sizeof(rtmi_ray))) return rc;
   if (int rc = ctx->spectra_out.reserve(chunk * RT_NBINS * sizeof(float))) return rc;
-  DeviceStats* ds = ctx->ws.stats;
+  DeviceStats* ds = ctx->wsm[0].ws.stats;
   HIP_TRY(hipMemset(ds, 0, sizeof *ds));
-  s->counting = false; s->last_stats = ds;
+  s->counting = false;
+  for (auto& b : s->last_stats) b = nullptr;
+  s->last_stats[0] = ds;
   KernelClock clock;
   uint32_t launches = 0, batches = 0;
   for (size_t at = 0; at < n; at += chunk) {
@@ -795,7 +820,7 @@ extern "C" int rtmi_trace_batch(rtmi_scene* s, const rtmi_ray* rays, size_t n, u
     b.integrator = integrator; b.max_depth = max_depth; b.seed = seed;
     b.sample0 = sample_index; b.n_samples = 1;
     b.rays = ctx->rays.as<double>(); b.n_rays = uint32_t(m); b.pixel_base = pixel_base + uint32_t(at);
-    if (int rc = run_batch(s, ctx->ws, b, m, ctx->spectra_out.as<float>(), nullptr, clock, launches)) return rc;
+    if (int rc = run_batch(s, ctx->wsm[0].ws, b, m, ctx->spectra_out.as<float>(), nullptr, clock, launches)) return rc;
     HIP_TRY(hipMemcpy(spectra + at * RT_NBINS, ctx->spectra_out.p, m * RT_NBINS * sizeof(float), hipMemcpyDeviceToHost));
     ++batches;
   }
@@ -857,13 +882,25 @@ int plan_render(rtmi_scene* s, const rtmi_camera* cam, const rtmi_render_params*
   return RTMI_OK;
 }
 
-// The batches of one render in workspace `ws`: runs of tiles x runs of samples, each at most tiles_per_batch x
-// samples_per_batch paths; every batch ends by adding its contributions to the per-pixel sums.
-int render_batches(rtmi_scene* s, const Workspace& ws, const rtmi_camera* cam, const rtmi_render_params* p, const RenderPlan& r,
-                   uint32_t tiles_per_batch, uint32_t samples_per_batch, float* dev_xyz_sum, hipStream_t stream, const Timer& timer) {
-  launch_fill_tiles(ws.tiles, r.n_tiles, r.first, r.stride, stream);
-  HIP_TRY(hipMemsetAsync(ws.stats, 0, sizeof(DeviceStats), stream));
-  s->last_stats = ws.stats;
+// The batches of one render: runs of tiles x runs of samples, each at most tiles_per_batch x samples_per_batch paths;
+// every batch ends by adding its contributions to the per-pixel sums. With one workspace everything runs on `stream`.
+// With two, batch i runs in workspace i % 2 on the context's internal stream i % 2, while the additions to the per-pixel
+// sums stay on `stream`, in batch order (so the sums do not depend on how the batches overlapped); `stream` is forked
+// into the two lanes at the start and has joined them again when the last addition has been issued.
+int render_batches(rtmi_scene* s, const Workspace* const* wss, int n_ws, const rtmi_camera* cam, const rtmi_render_params* p,
+                   const RenderPlan& r, uint32_t tiles_per_batch, uint32_t samples_per_batch, float* dev_xyz_sum, hipStream_t stream,
+                   const Timer& timer) {
+  rtmi_ctx* ctx = s->ctx;
+  launch_fill_tiles(wss[0]->tiles, r.n_tiles, r.first, r.stride, stream);
+  for (auto& b : s->last_stats) b = nullptr;
+  for (int w = 0; w < n_ws; ++w) {
+    HIP_TRY(hipMemsetAsync(wss[w]->stats, 0, sizeof(DeviceStats), stream));
+    s->last_stats[w] = wss[w]->stats;
+  }
+  if (n_ws > 1) {
+    HIP_TRY(hipEventRecord(ctx->ev_fork, stream));
+    for (int w = 0; w < n_ws; ++w) HIP_TRY(hipStreamWaitEvent(ctx->lane[w], ctx->ev_fork, 0));
+  }
   KernelClock clock;
   clock.on = (p->flags & RTMI_FLAG_TIME_KERNELS) != 0;
   clock.stream = stream;
@@ -873,6 +910,9 @@ int render_batches(rtmi_scene* s, const Workspace& ws, const rtmi_camera* cam, c
   for (uint32_t t0 = 0; t0 < r.n_tiles; t0 += tiles_per_batch) {
     const uint32_t nt = std::min(tiles_per_batch, r.n_tiles - t0);
     for (uint32_t s0 = r.s_begin; s0 < r.s_end; s0 += samples_per_batch) {
+      const int w = n_ws > 1 ? int(batches % uint32_t(n_ws)) : 0;
+      const Workspace& ws = *wss[w];
+      hipStream_t lane = n_ws > 1 ? ctx->lane[w] : stream;
       BatchDesc b{};
       b.cam = to_dev_camera(*cam);
       b.tile_list = ws.tiles + t0; b.n_tiles = nt; b.tile_size = r.T; b.tiles_y = r.tiles_y;
@@ -882,9 +922,16 @@ int render_batches(rtmi_scene* s, const Workspace& ws, const rtmi_camera* cam, c
       b.sample0 = s0; b.n_samples = std::min(samples_per_batch, r.s_end - s0);
       b.integrator = p->integrator; b.max_depth = p->max_depth; b.seed = p->seed;
       const size_t n_paths = size_t(b.n_local_pixels) * b.n_samples;
-      if (int rc = run_batch(s, ws, b, n_paths, nullptr, stream, clock, launches)) return rc;
+      // the workspace is free again once the batch that last used it has been added to the sums
+      if (n_ws > 1 && batches >= uint32_t(n_ws)) HIP_TRY(hipStreamWaitEvent(lane, ctx->ev_resolved[w], 0));
+      if (int rc = run_batch(s, ws, b, n_paths, nullptr, lane, clock, launches)) return rc;
+      if (n_ws > 1) {
+        HIP_TRY(hipEventRecord(ctx->ev_done[w], lane));
+        HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done[w], 0));
+      }
       launch_resolve(b, TraceOutputs{ws.contrib, ws.contrib + n_paths, ws.contrib + 2 * n_paths, nullptr, EmitQueue{}, nullptr, 0}, dev_xyz_sum, stream);
       HIP_TRY(hipGetLastError());
+      if (n_ws > 1) HIP_TRY(hipEventRecord(ctx->ev_resolved[w], stream));
       if (clock.on) kernel_ms += clock.drain();
       ++batches;
     }
@@ -906,16 +953,30 @@ extern "C" int rtmi_render_accumulate(rtmi_scene* s, const rtmi_camera* cam, con
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   Timer timer;
   const uint32_t n_samples = r.s_end - r.s_begin;
-  if (r.n_tiles == 0 || n_samples == 0) { s->last_stats = nullptr; if (stats) *stats = s->pending; return RTMI_OK; }
+  if (r.n_tiles == 0 || n_samples == 0) { for (auto& b : s->last_stats) b = nullptr; if (stats) *stats = s->pending; return RTMI_OK; }
 
   const uint64_t per_tile = uint64_t(r.T) * r.T;
+  // Instrumented renders keep to one lane (their events and counters describe one launch at a time).
+  const int lanes = (p->flags & (RTMI_FLAG_TIME_KERNELS | RTMI_FLAG_COUNT_TRAVERSAL)) ? 1 : ctx->n_lanes;
   uint32_t tiles_per_batch = 0, samples_per_batch = 0;
+  int n_ws = 1;
   for (;;) {
-    const uint64_t cap = std::max<uint64_t>(ctx->max_batch_paths, per_tile);
+    uint64_t cap = std::max<uint64_t>(ctx->max_batch_paths, per_tile);
+    // A render that fits one batch is cut into one batch per lane when it is large enough for every part to fill the
+    // chip many times over: the parts overlap where a single batch's launches would each drain to a thin tail.
+    const uint64_t all_paths = uint64_t(r.n_tiles) * per_tile * n_samples;
+    if (lanes > 1 && all_paths <= cap && all_paths >= (uint64_t(lanes) << 23)) {
+      const uint32_t parts = uint32_t(lanes);
+      if (n_samples >= parts) cap = uint64_t(r.n_tiles) * per_tile * ((n_samples + parts - 1) / parts);
+      else if (r.n_tiles >= parts) cap = uint64_t((r.n_tiles + parts - 1) / parts) * per_tile;
+    }
     tiles_per_batch = uint32_t(std::min<uint64_t>(r.n_tiles, cap / per_tile));
     samples_per_batch = uint32_t(std::min<uint64_t>(n_samples, std::max<uint64_t>(1, cap / (tiles_per_batch * per_tile))));
     const size_t batch_paths = size_t(tiles_per_batch) * per_tile * samples_per_batch;
-    const int rc = ensure_workspace(ctx, batch_paths, samples_per_batch, r.deep, r.want_queues);
+    const uint64_t n_batches = ((r.n_tiles + tiles_per_batch - 1) / tiles_per_batch) * uint64_t((n_samples + samples_per_batch - 1) / samples_per_batch);
+    n_ws = int(std::min<uint64_t>(uint64_t(lanes), n_batches));
+    int rc = RTMI_OK;
+    for (int w = 0; w < n_ws && rc == RTMI_OK; ++w) rc = ensure_workspace(ctx->wsm[w], batch_paths, samples_per_batch, r.deep, r.want_queues);
     if (rc == RTMI_OK) break;
     // The default batch is sized for an otherwise empty 288 GB device. If the workspace does not fit, halve the
     // batch (the image does not depend on it) rather than fail; a caller-chosen cap is never second-guessed.
@@ -925,8 +986,9 @@ extern "C" int rtmi_render_accumulate(rtmi_scene* s, const rtmi_camera* cam, con
     ctx->max_batch_paths >>= 1;
   }
   if (int rc = ctx->tiles.reserve(size_t(r.n_tiles) * sizeof(uint32_t))) return rc;
-  ctx->ws.tiles = ctx->tiles.as<uint32_t>();
-  if (int rc = render_batches(s, ctx->ws, cam, p, r, tiles_per_batch, samples_per_batch, dev_xyz_sum, stream, timer)) return rc;
+  const Workspace* wss[kMaxLanes];
+  for (int w = 0; w < kMaxLanes; ++w) { ctx->wsm[w].ws.tiles = ctx->tiles.as<uint32_t>(); wss[w] = &ctx->wsm[w].ws; }
+  if (int rc = render_batches(s, wss, n_ws, cam, p, r, tiles_per_batch, samples_per_batch, dev_xyz_sum, stream, timer)) return rc;
   if (stats) {
     if ((p->flags & RTMI_FLAG_TIME_KERNELS) || s->counting) return rtmi_render_collect_stats(s, stream_, stats);
     *stats = s->pending;
@@ -977,11 +1039,12 @@ extern "C" int rtmi_render_accumulate_noalloc(rtmi_scene* s, const rtmi_camera* 
   if (!carve_static_workspace(ctx->scratch, ws)) return fail(RTMI_INTERNAL, "the static workspace layout exceeds the scratch array");
   Timer timer;
   const uint32_t n_samples = r.s_end - r.s_begin;
-  if (r.n_tiles == 0 || n_samples == 0) { s->last_stats = nullptr; return RTMI_OK; }
+  if (r.n_tiles == 0 || n_samples == 0) { for (auto& b : s->last_stats) b = nullptr; return RTMI_OK; }
   const uint32_t tiles_per_batch = uint32_t(std::min<uint64_t>(r.n_tiles, kStaticBatchPaths / per_tile));
   const uint32_t samples_per_batch = uint32_t(std::min<uint64_t>(std::min<uint32_t>(n_samples, kStaticMaxSamplesPerBatch),
                                                                  std::max<uint64_t>(1, kStaticBatchPaths / (tiles_per_batch * per_tile))));
-  return render_batches(s, ws, cam, p, r, tiles_per_batch, samples_per_batch, dev_xyz_sum, static_cast<hipStream_t>(stream_), timer);
+  const Workspace* wss[1] = {&ws};
+  return render_batches(s, wss, 1, cam, p, r, tiles_per_batch, samples_per_batch, dev_xyz_sum, static_cast<hipStream_t>(stream_), timer);
 }
 
 extern "C" int rtmi_render_collect_stats(rtmi_scene* s, void* stream_, rtmi_stats* stats) {
@@ -989,20 +1052,24 @@ extern "C" int rtmi_render_collect_stats(rtmi_scene* s, void* stream_, rtmi_stat
   if (!stats) return fail(RTMI_BAD_ARG, "stats is NULL");
   HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream_)));
   *stats = s->pending;
-  if (s->last_stats) {
+  TraversalCounters trav{};
+  for (DeviceStats* block : s->last_stats) {
+    if (!block) continue;
     DeviceStats h;
-    HIP_TRY(hipMemcpy(&h, s->last_stats, sizeof h, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&h, block, sizeof h, hipMemcpyDeviceToHost));
     if (h.overflow)
       return fail(RTMI_INTERNAL, "a path-queue region overflowed and paths were dropped: the image of this render is incomplete "
                                  "(internal sizing error; please report the scene and the batch size)");
     stats->segments += h.bounce_segments;
-    stats->nodes_visited = h.trav.nodes; stats->prims_tested = h.trav.prims; stats->mesh_rays = h.mesh_rays;
-    if (getenv("RTMI_VERBOSE") && h.trav.node_slots)
-      std::fprintf(stderr, "rtmi: traversal lane occupancy: node loop %.1f %% (%llu steps), triangle loop %.1f %% (%llu tests), "
-                   "service block %.1f %% (%llu lanes)\n", 100.0 * h.trav.nodes / h.trav.node_slots, h.trav.nodes,
-                   100.0 * h.trav.prims / std::max(1ull, h.trav.prim_slots), h.trav.prims,
-                   100.0 * h.trav.service_lanes / std::max(1ull, h.trav.service_slots), h.trav.service_lanes);
+    stats->nodes_visited += h.trav.nodes; stats->prims_tested += h.trav.prims; stats->mesh_rays += h.mesh_rays;
+    trav.nodes += h.trav.nodes; trav.prims += h.trav.prims; trav.node_slots += h.trav.node_slots; trav.prim_slots += h.trav.prim_slots;
+    trav.service_slots += h.trav.service_slots; trav.service_lanes += h.trav.service_lanes;
   }
+  if (getenv("RTMI_VERBOSE") && trav.node_slots)
+    std::fprintf(stderr, "rtmi: traversal lane occupancy: node loop %.1f %% (%llu steps), triangle loop %.1f %% (%llu tests), "
+                 "service block %.1f %% (%llu lanes)\n", 100.0 * trav.nodes / trav.node_slots, trav.nodes,
+                 100.0 * trav.prims / std::max(1ull, trav.prim_slots), trav.prims,
+                 100.0 * trav.service_lanes / std::max(1ull, trav.service_slots), trav.service_lanes);
   return RTMI_OK;
 }
 

@@ -138,6 +138,7 @@ def test_trace_batch_aov(ctx, integrator):
 @pytest.mark.parametrize("name,integrator,depth,spp", [
     ("scene1", O.INT_RANDOM_WALK, 10, 8), ("scene2", O.INT_RANDOM_WALK, 10, 4), ("scene3", O.INT_RANDOM_WALK, 10, 8),
     ("scene1", O.INT_ALBEDO, 0, 4), ("scene1", O.INT_NORMAL, 0, 4), ("scene3", O.INT_RANDOM_WALK, 32, 2),
+    ("mesh", O.INT_RANDOM_WALK, 10, 4), ("mesh", O.INT_NORMAL, 0, 2),
 ])
 def test_render_matches_oracle(ctx, name, integrator, depth, spp):
     """Whole images at matched spp and seed: 8-bit output and linear mean XYZ."""
