@@ -57,13 +57,13 @@ WORKLOADS = {
 }
 
 
-def build_scene(ctx, w, hit_rule, from_rgb=None, library=True, **override):
+def build_scene(ctx, w, hit_rule, from_rgb=None, library=True, scene_flags=0, **override):
     from raytracing_amd import api, scenes
     kw = {k: v for k, v in w.items() if k in ("width", "height", "specular_mesh")}
     kw.update(override)
     builder, cam_args = getattr(scenes, w["recipe"])(from_rgb=from_rgb, **kw)
     if library:
-        return api.Scene(ctx, *builder.arrays(), hit_rule=hit_rule), api.camera_new(*cam_args)
+        return api.Scene(ctx, *builder.arrays(), hit_rule=hit_rule, flags=scene_flags), api.camera_new(*cam_args)
     return builder, cam_args
 
 
@@ -257,6 +257,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every core this process may use)")
     ap.add_argument("--batch-paths", type=int, default=0, help="path slots per batch of launches (0 = library default)")
+    ap.add_argument("--gpu-bvh", action="store_true", help="build the meshes' trees on the GPU (Morton order + radix tree) instead of the host SAH build")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise the launcher, the rendezvous and the merge over gloo")
     args = ap.parse_args()
 
@@ -297,7 +298,7 @@ def main():
     hit_rule = L.HIT_FIRST_INDEX if args.rule == "first_index" else L.HIT_NEAREST
     ctx = api.Context(local_rank, args.batch_paths)
     t_build = time.perf_counter()
-    scene, cam = build_scene(ctx, w, hit_rule)
+    scene, cam = build_scene(ctx, w, hit_rule, scene_flags=L.SCENE_GPU_BVH if args.gpu_bvh else 0)
     build_s = time.perf_counter() - t_build
     width, height, spp, depth = cam.width, cam.height, w["spp"], w["depth"]
     spp_job = spp * world if args.partition == "samples" else spp     # weak scaling in samples
@@ -375,7 +376,8 @@ def main():
                        "spp_job": spp_job, "max_depth": depth, "integrator": "RandomWalk", "hit_rule": args.rule,
                        "partition": args.partition, "mesh_triangles": info["n_mesh_triangles"],
                        "segments_per_step_per_gpu": seg_step, "scene_build_s": build_s,
-                       "bvh_build_s": info.get("bvh_build_ms", 0.0) / 1e3},
+                       "bvh_build_s": info.get("bvh_build_ms", 0.0) / 1e3,
+                       "bvh_builder": "device_lbvh" if args.gpu_bvh else "host_sah"},
             "world_size": dist.get_world_size() if world > 1 else 1,
             "per_rank_ms_per_step": per_rank_ms,
             "ms_per_step_instrumented": instrumented_ms,

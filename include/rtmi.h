@@ -56,6 +56,12 @@ enum { RTMI_HIT_FIRST_INDEX = 0, RTMI_HIT_NEAREST = 1 };
 enum { RTMI_INT_RANDOM_WALK = 0, RTMI_INT_ALBEDO = 1, RTMI_INT_NORMAL = 2 };
 /* enum SpectrumType (src/spectrum/mod.rs:8-11) */
 enum { RTMI_SPEC_REFLECTANCE = 0, RTMI_SPEC_ILLUMINANT = 1 };
+/* rtmi_scene_desc.flags. The reference has no acceleration structure at all (src/shapes/model_obj.rs:77-87 scans every
+ * triangle); both builders only prune work and give the same hits. */
+enum {
+  RTMI_SCENE_GPU_BVH = 1   /* build the meshes' BVHs on the GPU (Morton order + radix tree: built in a tenth of the time of
+                              the default host SAH build, slower to traverse), for scenes that change between renders */
+};
 /* rtmi_render_params.flags */
 enum {
   RTMI_FLAG_TIME_KERNELS = 1,    /* bracket every closest-hit kernel with HIP events (adds host syncs) */
@@ -104,7 +110,7 @@ typedef struct {
   const rtmi_triangle* triangles; uint32_t n_triangles;
   const rtmi_material* materials; uint32_t n_materials;
   uint32_t hit_rule;  /* RTMI_HIT_* */
-  uint32_t reserved;  /* 0 */
+  uint32_t flags;     /* RTMI_SCENE_* */
 } rtmi_scene_desc;
 
 /* Camera (src/camera.rs:4-9): focus and the screen rectangle (p1 top-left, p2 top-right,
@@ -144,6 +150,7 @@ typedef struct {
   uint32_t n_nodes, max_depth, n_mesh_triangles, n_spectra;
   uint64_t node_bytes, triangle_bytes;
   double bvh_build_ms;   /* host wall time rtmi_scene_create spent building the BVHs of the scene's models */
+  double bvh_device_ms;  /* the part of it inside the device builder (RTMI_SCENE_GPU_BVH), copies to and from the device included */
   double upload_ms;      /* ... and flattening the rest and copying everything to the device */
 } rtmi_scene_info;
 

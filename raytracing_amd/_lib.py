@@ -27,6 +27,7 @@ INT_RANDOM_WALK, INT_ALBEDO, INT_NORMAL = 0, 1, 2
 SPEC_REFLECTANCE, SPEC_ILLUMINANT = 0, 1
 FLAG_TIME_KERNELS, FLAG_COUNT_TRAVERSAL = 1, 2
 PARTITION_SAMPLES, PARTITION_TILES = 0, 1
+SCENE_GPU_BVH = 1
 
 # numpy record layouts of the plain C structs
 RAY_DT = np.dtype([("o", "<f8", 3), ("d", "<f8", 3)])
@@ -44,7 +45,7 @@ class SceneDesc(C.Structure):
                 ("spheres", C.c_void_p), ("n_spheres", C.c_uint32),
                 ("triangles", C.c_void_p), ("n_triangles", C.c_uint32),
                 ("materials", C.c_void_p), ("n_materials", C.c_uint32),
-                ("hit_rule", C.c_uint32), ("reserved", C.c_uint32)]
+                ("hit_rule", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class Camera(C.Structure):
@@ -74,7 +75,7 @@ class MultiInfo(C.Structure):
 
 class SceneInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("max_depth", C.c_uint32), ("n_mesh_triangles", C.c_uint32), ("n_spectra", C.c_uint32),
-                ("node_bytes", C.c_uint64), ("triangle_bytes", C.c_uint64), ("bvh_build_ms", C.c_double), ("upload_ms", C.c_double)]
+                ("node_bytes", C.c_uint64), ("triangle_bytes", C.c_uint64), ("bvh_build_ms", C.c_double), ("bvh_device_ms", C.c_double), ("upload_ms", C.c_double)]
 
 
 # every symbol include/rtmi.h declares: name -> (restype, argtypes)

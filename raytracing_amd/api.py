@@ -88,14 +88,14 @@ class Context:
 class Scene:
     """A flattened scene resident on the context's GPU (rtmi_scene_create)."""
 
-    def __init__(self, ctx, objects, spheres, triangles, materials, hit_rule=L.HIT_FIRST_INDEX):
+    def __init__(self, ctx, objects, spheres, triangles, materials, hit_rule=L.HIT_FIRST_INDEX, flags=0):
         self.ctx = ctx
         objects = np.ascontiguousarray(objects, dtype=L.OBJECT_DT)
         spheres = np.ascontiguousarray(spheres, dtype=L.SPHERE_DT)
         triangles = np.ascontiguousarray(triangles, dtype=L.TRIANGLE_DT)
         materials = np.ascontiguousarray(materials, dtype=L.MATERIAL_DT)
         d = L.SceneDesc(objects.ctypes.data, len(objects), spheres.ctypes.data, len(spheres), triangles.ctypes.data,
-                        len(triangles), materials.ctypes.data, len(materials), int(hit_rule), 0)
+                        len(triangles), materials.ctypes.data, len(materials), int(hit_rule), int(flags))
         h = C.c_void_p()
         L.check(L.lib().rtmi_scene_create(ctx.handle, C.byref(d), C.byref(h)))
         self.handle = h

@@ -1,5 +1,6 @@
 // bvh.cpp -- binned-SAH BVH2 builder (host). See bvh.h.
 #include "bvh.h"
+#include "bvh_quant.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -212,37 +213,7 @@ QuantizedNodes quantize_nodes(const BvhBuild& build, int format) {
     }
   double widest = 0.0;
   for (int k = 0; k < 3; ++k) if (hi[k] >= lo[k]) widest = std::max(widest, hi[k] - lo[k]);
-  for (int k = 0; k < 3; ++k) {
-    if (!(hi[k] >= lo[k])) { lo[k] = hi[k] = 0.0; }
-    // 65 535 levels; the boxes use 4 .. 65 531 so that the outward safety steps below never leave the range. An axis
-    // the mesh is flat along still gets a positive step.
-    double step = std::max((hi[k] - lo[k]) / 65520.0, std::max(widest * 0x1.0p-30, 1e-30));
-    float fs = float(step);
-    if (double(fs) < step) fs = std::nextafterf(fs, FLT_MAX);
-    float fl = float(lo[k] - 6.0 * double(fs));
-    if (double(fl) > lo[k] - 6.0 * double(fs)) fl = std::nextafterf(fl, -FLT_MAX);
-    q.grid_lo[k] = fl; q.grid_step[k] = fs;
-  }
-  auto quant_lo = [&](double v, int k) {   // largest level whose plane is at least one step below v
-    const double g = double(q.grid_lo[k]), s = double(q.grid_step[k]);
-    long t = long(std::floor((v - g) / s)) - 1;
-    while (t > 0 && g + double(t) * s > v - s) --t;
-    return uint32_t(std::min(65535L, std::max(0L, t)));
-  };
-  auto quant_hi = [&](double v, int k) {   // smallest level whose plane is at least one step above v
-    const double g = double(q.grid_lo[k]), s = double(q.grid_step[k]);
-    long t = long(std::ceil((v - g) / s)) + 1;
-    while (t < 65535 && g + double(t) * s < v + s) ++t;
-    return uint32_t(std::min(65535L, std::max(0L, t)));
-  };
-  auto small_ref = [](uint32_t ref) -> uint32_t {
-    if (ref == RT_REF_NONE) return RT_SMALL_REF_NONE;
-    if (ref & RT_LEAF_FLAG) {
-      const uint32_t first = (ref & ~RT_LEAF_FLAG) >> 4, count = ref & 15u;   // count 1..4, first <= RT_SMALL_MAX_TRIS
-      return RT_SMALL_LEAF_FLAG | (first << 2) | (count - 1u);
-    }
-    return ref;   // node index < 0x8000
-  };
+  for (int k = 0; k < 3; ++k) quant_grid_axis(lo[k], hi[k], widest, &q.grid_lo[k], &q.grid_step[k]);
   const uint32_t w4 = node_words4(format);
   q.words.assign(build.nodes.size() * w4, RtWord4{0, 0, 0, 0});
   for (size_t i = 0; i < build.nodes.size(); ++i) {
@@ -252,20 +223,11 @@ QuantizedNodes quantize_nodes(const BvhBuild& build, int format) {
       const bool none = (c ? n.ref1 : n.ref0) == RT_REF_NONE;
       const float* l = c ? n.lo1 : n.lo0; const float* h = c ? n.hi1 : n.hi0;
       for (int k = 0; k < 3; ++k) {
-        b[c * 6 + k] = none ? 65535u : quant_lo(double(l[k]), k);        // an empty slot's box is inside out
-        b[c * 6 + 3 + k] = none ? 0u : quant_hi(double(h[k]), k);
+        b[c * 6 + k] = none ? 65535u : quant_level_lo(double(l[k]), q.grid_lo[k], q.grid_step[k]);   // an empty slot's box is inside out
+        b[c * 6 + 3 + k] = none ? 0u : quant_level_hi(double(h[k]), q.grid_lo[k], q.grid_step[k]);
       }
     }
-    RtWord4* w = &q.words[i * w4];
-    w[0] = RtWord4{b[0] | b[1] << 16, b[2] | b[3] << 16, b[4] | b[5] << 16, b[6] | b[7] << 16};
-    w[1].x = b[8] | b[9] << 16; w[1].y = b[10] | b[11] << 16;
-    if (format == RT_NODES_SMALL) {
-      w[1].z = small_ref(n.ref0) | small_ref(n.ref1) << 16;
-      w[1].w = std::min(n.min_index0, 0xFFFFu) | std::min(n.min_index1, 0xFFFFu) << 16;
-    } else {
-      w[1].z = n.ref0; w[1].w = n.ref1;
-      if (format == RT_NODES_WIDE) w[2] = RtWord4{n.min_index0, n.min_index1, 0, 0};
-    }
+    pack_node(&q.words[i * w4], format, b, n.ref0, n.ref1, n.min_index0, n.min_index1);
   }
   return q;
 }

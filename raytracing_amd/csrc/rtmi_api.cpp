@@ -16,6 +16,7 @@
 
 #include "../../include/rtmi.h"
 #include "bvh.h"
+#include "lbvh.h"
 #include "rt_kernels.h"
 #include "rt_types.h"
 #include "spectrum.h"
@@ -567,6 +568,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   *out = nullptr;
   if (int rc = bind(ctx)) return rc;
   if (d->hit_rule != RTMI_HIT_FIRST_INDEX && d->hit_rule != RTMI_HIT_NEAREST) return fail(RTMI_BAD_ARG, "unknown hit rule %u", d->hit_rule);
+  if (d->flags & ~uint32_t(RTMI_SCENE_GPU_BVH)) return fail(RTMI_BAD_ARG, "unknown scene flags %#x", d->flags);
   if ((d->n_objects && !d->objects) || (d->n_spheres && !d->spheres) || (d->n_triangles && !d->triangles) ||
       (d->n_materials && !d->materials))
     return fail(RTMI_BAD_ARG, "a non-empty array is NULL");
@@ -599,9 +601,17 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   std::vector<DevObject> objects(d->n_objects);
   std::vector<DevSphere> spheres;
   std::vector<DevTopTri> top_tris;
-  std::vector<BvhBuild> builds;      // one per model, in mesh_objects order (their triangles moved out)
   std::vector<RtWord4> nodes;        // the quantised nodes of every model
-  uint32_t n_nodes = 0, largest_mesh = 0, largest_leaf = 0;
+  uint32_t n_nodes = 0, largest_mesh = 0;
+  constexpr uint32_t kLeafSize = 4;  // the 16-bit leaf references of RT_NODES_SMALL count up to 4
+  for (uint32_t i = 0; i < d->n_objects; ++i)
+    if (d->objects[i].kind == RTMI_OBJ_MODEL) largest_mesh = std::max(largest_mesh, d->objects[i].count);
+  // One node format per scene (the kernels are instantiated per format): the 32-byte form with 16-bit references when
+  // every mesh is small enough, else 32 bytes without minimum indices under the nearest rule, else 48 bytes.
+  const int node_format = largest_mesh <= RT_SMALL_MAX_TRIS ? RT_NODES_SMALL
+                        : d->hit_rule == RTMI_HIT_NEAREST ? RT_NODES_NEAREST : RT_NODES_WIDE;
+  const bool gpu_bvh = (d->flags & RTMI_SCENE_GPU_BVH) != 0;
+  double bvh_device_ms = 0.0;
   std::vector<DevMeshTri> mesh_tris;
   std::vector<DevTriFrame> mesh_frames;
   std::vector<uint32_t> mesh_objects;
@@ -653,47 +663,51 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
       if (uint64_t(o.first) + o.count > d->n_triangles) return fail(RTMI_BAD_ARG, "object %u: triangles [%u,+%u) out of range", i, o.first, o.count);
       if (o.count >= (1u << 27)) return fail(RTMI_UNSUPPORTED, "object %u: %u triangles in one mesh", i, o.count);
       Timer bvh_timer;
-      constexpr uint32_t leaf_size = 4;   // the 16-bit leaf references of RT_NODES_SMALL count up to 4
-      BvhBuild bb = build_bvh(o.count ? d->triangles[o.first].v : nullptr, o.count, leaf_size);
-      largest_leaf = std::max(largest_leaf, leaf_size);
-      bvh_build_ms += bvh_timer.ms();
-      dobj.root = n_nodes;          // in nodes; the quantised words are laid out once the scene's node format is known
+      dobj.root = n_nodes;          // in nodes of the scene's format
       dobj.first = uint32_t(mesh_tris.size());
-      std::memcpy(dobj.center, bb.center, sizeof dobj.center);
-      dobj.radius = bb.radius;
-      for (int k = 0; k < 3; ++k) {   // union of the root's two child boxes, which are already padded and rounded outward
-        const BvhNode& r = bb.nodes[0];
-        dobj.box_lo[k] = std::min(r.lo0[k], r.lo1[k]);
-        dobj.box_hi[k] = std::max(r.hi0[k], r.hi1[k]);
+      const double* verts = o.count ? d->triangles[o.first].v : nullptr;
+      if (gpu_bvh && o.count >= 2) {
+        // Morton order + radix tree, built on the device (lbvh.hip); the same records come back as the host builder makes
+        LbvhOut lb;
+        std::string why;
+        const hipError_t e = build_lbvh(verts, o.count, node_format, &lb, &why);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RTMI_OOM : RTMI_HIP_ERROR, "object %u: device BVH build: %s", i, why.c_str());
+        std::memcpy(dobj.center, lb.center, sizeof dobj.center);
+        dobj.radius = lb.radius;
+        for (int k = 0; k < 3; ++k) {
+          dobj.box_lo[k] = lb.box_lo[k]; dobj.box_hi[k] = lb.box_hi[k];
+          dobj.grid_lo[k] = lb.grid_lo[k]; dobj.grid_step[k] = lb.grid_step[k];
+        }
+        n_nodes += lb.n_nodes;
+        nodes.insert(nodes.end(), lb.words.begin(), lb.words.end());
+        mesh_tris.insert(mesh_tris.end(), lb.tris.begin(), lb.tris.end());
+        mesh_frames.insert(mesh_frames.end(), lb.frames.begin(), lb.frames.end());
+        max_depth = std::max(max_depth, lb.max_depth);
+        bvh_device_ms += lb.device_ms;
+      } else {
+        BvhBuild bb = build_bvh(verts, o.count, kLeafSize);
+        std::memcpy(dobj.center, bb.center, sizeof dobj.center);
+        dobj.radius = bb.radius;
+        for (int k = 0; k < 3; ++k) {   // union of the root's two child boxes, which are already padded and rounded outward
+          const BvhNode& r = bb.nodes[0];
+          dobj.box_lo[k] = std::min(r.lo0[k], r.lo1[k]);
+          dobj.box_hi[k] = std::max(r.hi0[k], r.hi1[k]);
+        }
+        const QuantizedNodes q = quantize_nodes(bb, node_format);
+        for (int k = 0; k < 3; ++k) { dobj.grid_lo[k] = q.grid_lo[k]; dobj.grid_step[k] = q.grid_step[k]; }
+        n_nodes += uint32_t(bb.nodes.size());
+        nodes.insert(nodes.end(), q.words.begin(), q.words.end());
+        mesh_tris.insert(mesh_tris.end(), bb.tris.begin(), bb.tris.end());
+        for (const DevMeshTri& t : bb.tris) mesh_frames.push_back(tri_frame(t.v));
+        max_depth = std::max(max_depth, bb.max_depth);
       }
-      set_model_gate(dobj, o.count ? d->triangles[o.first].v : nullptr, o.count, bb.radius);
+      set_model_gate(dobj, verts, o.count, dobj.radius);
       mesh_objects.push_back(i);
-      n_nodes += uint32_t(bb.nodes.size());
-      largest_mesh = std::max(largest_mesh, o.count);
-      mesh_tris.insert(mesh_tris.end(), bb.tris.begin(), bb.tris.end());
-      for (const DevMeshTri& t : bb.tris) mesh_frames.push_back(tri_frame(t.v));
-      max_depth = std::max(max_depth, bb.max_depth);
-      bb.tris.clear(); bb.tris.shrink_to_fit();
-      builds.push_back(std::move(bb));
+      bvh_build_ms += bvh_timer.ms();
     } else {
       return fail(RTMI_UNSUPPORTED, "object %u has unknown kind %u", i, o.kind);
     }
     objects[i] = dobj;
-  }
-  // One node format per scene (the kernels are instantiated per format): the 32-byte form with 16-bit references when
-  // every mesh is small enough, else 32 bytes without minimum indices under the nearest rule, else 48 bytes.
-  const int node_format = largest_mesh <= RT_SMALL_MAX_TRIS && largest_leaf <= 4 ? RT_NODES_SMALL
-                        : d->hit_rule == RTMI_HIT_NEAREST ? RT_NODES_NEAREST : RT_NODES_WIDE;
-  {
-    Timer quant_timer;
-    for (size_t m = 0; m < builds.size(); ++m) {
-      const QuantizedNodes q = quantize_nodes(builds[m], node_format);
-      DevObject& ob = objects[mesh_objects[m]];
-      for (int k = 0; k < 3; ++k) { ob.grid_lo[k] = q.grid_lo[k]; ob.grid_step[k] = q.grid_step[k]; }
-      nodes.insert(nodes.end(), q.words.begin(), q.words.end());
-      builds[m] = BvhBuild{};
-    }
-    bvh_build_ms += quant_timer.ms();
   }
   const uint32_t stack_entries = n_nodes == 0 ? 0 : max_depth + 1;
   const size_t stack_lds = size_t(stack_entries) * kBlock * sizeof(uint32_t);
@@ -727,6 +741,7 @@ extern "C" int rtmi_scene_create(rtmi_ctx* ctx, const rtmi_scene_desc* d, rtmi_s
   s->info.n_nodes = n_nodes; s->info.max_depth = max_depth;
   s->info.n_mesh_triangles = uint32_t(mesh_tris.size()); s->info.n_spectra = s->dev.n_spectra;
   s->info.node_bytes = nodes.size() * sizeof(RtWord4); s->info.triangle_bytes = mesh_tris.size() * (sizeof(DevMeshTri) + sizeof(DevTriFrame));
+  s->info.bvh_device_ms = bvh_device_ms;
   s->info.bvh_build_ms = bvh_build_ms; s->info.upload_ms = create_timer.ms() - bvh_build_ms;
   *out = s.release();
   return RTMI_OK;

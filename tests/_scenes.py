@@ -13,10 +13,10 @@ def oracle_scene(recipe, hit_rule=O.HIT_FIRST_INDEX, **kw):
     return O.Scene(*b.arrays(), hit_rule=hit_rule), O.camera(*cam_args), cam_args
 
 
-def library_scene(ctx, recipe, hit_rule=0, **kw):
+def library_scene(ctx, recipe, hit_rule=0, flags=0, **kw):
     from raytracing_amd import api
     b, cam_args = recipe(from_rgb=None, **kw)
-    return api.Scene(ctx, *b.arrays(), hit_rule=hit_rule), api.camera_new(*cam_args), cam_args
+    return api.Scene(ctx, *b.arrays(), hit_rule=hit_rule, flags=flags), api.camera_new(*cam_args), cam_args
 
 
 def primary_rays(cam, step=1):
