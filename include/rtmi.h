@@ -258,6 +258,14 @@ int rtmi_multi_info(const rtmi_multi* multi, rtmi_multi_info_t* out);
 int rtmi_multi_render(rtmi_multi* multi, const rtmi_camera* cam, const rtmi_render_params* params, uint32_t partition,
                       uint8_t* host_rgb8, float* host_xyz, rtmi_stats* stats, rtmi_stats* per_rank_stats);
 
+/* Progressive form of rtmi_multi_render: the spp samples are taken in n_passes calls (pass = 0 .. n_passes-1, in order;
+ * pass p renders the p-th of n_passes balanced sample ranges, shared out over the devices as above). Every call ends
+ * with the reduce and the tone map, so it returns the image of all samples taken so far (their mean); after the last
+ * pass that is the image rtmi_multi_render gives -- bit for bit under RTMI_PARTITION_TILES. The devices keep their own
+ * sums between the calls; pass 0 clears them. The reference renders all-or-nothing (src/main.rs:79,88,97). */
+int rtmi_multi_render_pass(rtmi_multi* multi, const rtmi_camera* cam, const rtmi_render_params* params, uint32_t partition,
+                           uint32_t pass, uint32_t n_passes, uint8_t* host_rgb8, float* host_xyz, rtmi_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,8 @@ SYMBOLS = {
     "rtmi_multi_info": (C.c_int, [C.c_void_p, C.POINTER(MultiInfo)]),
     "rtmi_multi_render": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_uint32, C.c_void_p, C.c_void_p,
                                     C.POINTER(Stats), C.POINTER(Stats)]),
+    "rtmi_multi_render_pass": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
     "rtmi_tonemap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
 }
 

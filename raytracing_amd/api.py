@@ -203,3 +203,13 @@ class MultiScene:
         L.check(L.lib().rtmi_multi_render(self.handle, C.byref(cam), C.byref(params), int(partition), rgb8.ctypes.data,
                                           xyz.ctypes.data if want_xyz else None, C.byref(st), per))
         return rgb8, xyz, stats_dict(st), [stats_dict(p) for p in per]
+
+    def render_pass(self, cam, params, partition, pass_index, n_passes, want_xyz=True):
+        """One pass of a progressive render; returns the image of all the samples taken so far."""
+        w, h = cam.width, cam.height
+        rgb8 = np.zeros((h, w, 3), dtype=np.uint8)
+        xyz = np.zeros((h, w, 3), dtype=np.float32) if want_xyz else None
+        st = L.Stats()
+        L.check(L.lib().rtmi_multi_render_pass(self.handle, C.byref(cam), C.byref(params), int(partition), int(pass_index), int(n_passes),
+                                               rgb8.ctypes.data, xyz.ctypes.data if want_xyz else None, C.byref(st)))
+        return rgb8, xyz, stats_dict(st)

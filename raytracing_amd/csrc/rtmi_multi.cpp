@@ -114,6 +114,8 @@ struct Rank {
 struct rtmi_multi {
   std::vector<Rank> ranks;
   Rccl* rccl = nullptr;           // non-null: the merge is one ncclReduce per rank; null: copies to the first device and adds
+  float* total = nullptr;         // first device: the merged sums of a pass (the ranks' own sums stay apart for the next pass)
+  size_t total_floats = 0;
   float* staging = nullptr;       // first device: a peer's sums on their way into the total (merge without RCCL)
   size_t staging_floats = 0;
   uint8_t* rgb8 = nullptr;        // first device
@@ -140,6 +142,7 @@ extern "C" void rtmi_multi_destroy(rtmi_multi* m) {
   if (!m->ranks.empty()) {
     (void)hipSetDevice(m->ranks[0].device);
     if (m->staging) (void)hipFree(m->staging);
+    if (m->total) (void)hipFree(m->total);
     if (m->rgb8) (void)hipFree(m->rgb8);
   }
   delete m;
@@ -205,6 +208,11 @@ int ensure_rank_buffers(rtmi_multi* m, size_t n_pix) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->rgb8), n_pix * 3));
     m->rgb8_bytes = n_pix * 3;
   }
+  if (m->total_floats < n_pix * 3) {
+    if (m->total) { (void)hipFree(m->total); m->total = nullptr; m->total_floats = 0; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->total), n_pix * 3 * sizeof(float)));
+    m->total_floats = n_pix * 3;
+  }
   if (!m->rccl && m->ranks.size() > 1 && m->staging_floats < n_pix * 3) {
     if (m->staging) { (void)hipFree(m->staging); m->staging = nullptr; m->staging_floats = 0; }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->staging), n_pix * 3 * sizeof(float)));
@@ -213,60 +221,58 @@ int ensure_rank_buffers(rtmi_multi* m, size_t n_pix) {
   return RTMI_OK;
 }
 
-// One rank's leg of the render, on its own host thread: its share of the samples or tiles into its own buffer.
-void render_leg(Rank* r, const rtmi_camera* cam, rtmi_render_params p, size_t n_floats) {
+// One rank's leg of a pass, on its own host thread: its share of the samples or tiles added into its own buffer.
+void render_leg(Rank* r, const rtmi_camera* cam, rtmi_render_params p, size_t n_floats, bool clear) {
   r->rc = RTMI_OK; r->error.clear();
   auto check = [&](int rc) { if (rc != RTMI_OK && r->rc == RTMI_OK) { r->rc = rc; r->error = rtmi_last_error(); } return rc == RTMI_OK; };
   hipError_t e = hipSetDevice(r->device);
-  if (e == hipSuccess) e = hipMemsetAsync(r->sums, 0, n_floats * sizeof(float), r->stream);
+  if (e == hipSuccess && clear) e = hipMemsetAsync(r->sums, 0, n_floats * sizeof(float), r->stream);
   if (e != hipSuccess) { r->rc = RTMI_HIP_ERROR; r->error = hipGetErrorString(e); return; }
   if (!check(rtmi_render_accumulate(r->scene, cam, &p, r->sums, r->stream, nullptr))) return;
   check(rtmi_render_collect_stats(r->scene, r->stream, &r->stats));   // waits for the stream
 }
 
-}  // namespace
-
-extern "C" int rtmi_multi_render(rtmi_multi* m, const rtmi_camera* cam, const rtmi_render_params* params, uint32_t partition,
-                                 uint8_t* host_rgb8, float* host_xyz, rtmi_stats* stats, rtmi_stats* per_rank_stats) {
-  if (!m || !cam || !params) return fail(RTMI_BAD_ARG, "NULL argument");
-  if (!host_rgb8 && !host_xyz) return fail(RTMI_BAD_ARG, "no output buffer");
-  if (partition != RTMI_PARTITION_SAMPLES && partition != RTMI_PARTITION_TILES) return fail(RTMI_BAD_ARG, "unknown partition %u", partition);
-  if (params->sample_end || params->sample_begin || params->tile_world || params->tile_rank)
-    return fail(RTMI_BAD_ARG, "the partition fields of rtmi_render_params must be 0: rtmi_multi_render sets them per device");
-  if (cam->width == 0 || cam->height == 0) return fail(RTMI_BAD_ARG, "camera resolution %ux%u", cam->width, cam->height);
-  if (params->spp == 0) return fail(RTMI_BAD_ARG, "spp is 0");
+// Samples [s_begin, s_end) of the render described by `params`, shared out over the ranks and added to their sums
+// (cleared first when `clear`); then the one exchange: every rank's W * H * 3 sums reduced into `total` on the first
+// device, which is tone-mapped as the mean over `divisor` samples.
+int render_samples(rtmi_multi* m, const rtmi_camera* cam, const rtmi_render_params* params, uint32_t partition, uint32_t s_begin,
+                   uint32_t s_end, bool clear, uint32_t divisor, uint8_t* host_rgb8, float* host_xyz, rtmi_stats* stats,
+                   rtmi_stats* per_rank_stats) {
   Timer timer;
   const size_t n = m->ranks.size(), n_pix = size_t(cam->width) * cam->height;
   if (int rc = ensure_rank_buffers(m, n_pix)) return rc;
 
   // shares: contiguous balanced sample ranges (sizes differ by at most one), or tiles k with k % n == rank
   std::vector<std::thread> threads;
+  const uint32_t n_samples = s_end - s_begin;
   for (size_t i = 0; i < n; ++i) {
     rtmi_render_params p = *params;
     if (partition == RTMI_PARTITION_SAMPLES) {
-      const uint32_t base = params->spp / uint32_t(n), extra = params->spp % uint32_t(n);
-      const uint32_t begin = uint32_t(i) * base + std::min<uint32_t>(uint32_t(i), extra);
+      const uint32_t base = n_samples / uint32_t(n), extra = n_samples % uint32_t(n);
+      const uint32_t begin = s_begin + uint32_t(i) * base + std::min<uint32_t>(uint32_t(i), extra);
       const uint32_t end = begin + base + (i < extra ? 1u : 0u);
       p.sample_begin = begin; p.sample_end = end;
       // more ranks than samples: this rank gets an empty tile share (it still clears its buffer for the merge)
       if (end == begin) { p.sample_begin = p.sample_end = 0; p.tile_world = 0xFFFFFFFFu; p.tile_rank = 0xFFFFFFFEu; }
     } else {
       p.tile_rank = uint32_t(i); p.tile_world = uint32_t(n);
+      p.sample_begin = s_begin; p.sample_end = s_end;
+      if (s_begin == 0 && s_end == params->spp) p.sample_begin = p.sample_end = 0;
     }
-    threads.emplace_back(render_leg, &m->ranks[i], cam, p, n_pix * 3);
+    threads.emplace_back(render_leg, &m->ranks[i], cam, p, n_pix * 3, clear);
   }
   for (auto& t : threads) t.join();
   for (size_t i = 0; i < n; ++i)
     if (m->ranks[i].rc != RTMI_OK) return fail(m->ranks[i].rc, "device %d: %s", m->ranks[i].device, m->ranks[i].error.c_str());
 
-  // the one exchange of the render: every rank's W * H * 3 sums onto the first device
   Rank& root = m->ranks[0];
   if (m->rccl) {
     int rc = m->rccl->GroupStart();
     for (size_t i = 0; i < n && rc == 0; ++i) {
       Rank& r = m->ranks[i];
       HIP_TRY(hipSetDevice(r.device));
-      rc = m->rccl->Reduce(r.sums, r.sums, n_pix * 3, Rccl::kFloat32, Rccl::kSum, 0, r.comm, r.stream);
+      // the receive buffer only matters on the root; the ranks' own sums stay as they are for the next pass
+      rc = m->rccl->Reduce(r.sums, i == 0 ? m->total : r.sums, n_pix * 3, Rccl::kFloat32, Rccl::kSum, 0, r.comm, r.stream);
     }
     const int rc_end = m->rccl->GroupEnd();
     if (rc == 0) rc = rc_end;
@@ -274,6 +280,7 @@ extern "C" int rtmi_multi_render(rtmi_multi* m, const rtmi_camera* cam, const rt
     for (Rank& r : m->ranks) { HIP_TRY(hipSetDevice(r.device)); HIP_TRY(hipStreamSynchronize(r.stream)); }
   } else {
     HIP_TRY(hipSetDevice(root.device));
+    HIP_TRY(hipMemcpyAsync(m->total, root.sums, n_pix * 3 * sizeof(float), hipMemcpyDeviceToDevice, root.stream));
     for (size_t i = 1; i < n; ++i) {
       Rank& r = m->ranks[i];
       const float* src = r.sums;
@@ -281,7 +288,7 @@ extern "C" int rtmi_multi_render(rtmi_multi* m, const rtmi_camera* cam, const rt
         HIP_TRY(hipMemcpyPeerAsync(m->staging, root.device, r.sums, r.device, n_pix * 3 * sizeof(float), root.stream));
         src = m->staging;
       }
-      rtmi::launch_add(root.sums, src, n_pix * 3, root.stream);
+      rtmi::launch_add(m->total, src, n_pix * 3, root.stream);
       HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(root.stream));
@@ -289,13 +296,13 @@ extern "C" int rtmi_multi_render(rtmi_multi* m, const rtmi_camera* cam, const rt
 
   HIP_TRY(hipSetDevice(root.device));
   if (host_rgb8) {
-    if (int rc = rtmi_tonemap(root.ctx, root.sums, params->spp, cam->width, cam->height, m->rgb8, root.stream)) return rc;
+    if (int rc = rtmi_tonemap(root.ctx, m->total, divisor, cam->width, cam->height, m->rgb8, root.stream)) return rc;
     HIP_TRY(hipMemcpyAsync(host_rgb8, m->rgb8, n_pix * 3, hipMemcpyDeviceToHost, root.stream));
   }
-  if (host_xyz) HIP_TRY(hipMemcpyAsync(host_xyz, root.sums, n_pix * 3 * sizeof(float), hipMemcpyDeviceToHost, root.stream));
+  if (host_xyz) HIP_TRY(hipMemcpyAsync(host_xyz, m->total, n_pix * 3 * sizeof(float), hipMemcpyDeviceToHost, root.stream));
   HIP_TRY(hipStreamSynchronize(root.stream));
   if (host_xyz) {
-    const float spp = float(params->spp);
+    const float spp = float(divisor);
     for (size_t i = 0; i < n_pix * 3; ++i) host_xyz[i] /= spp;
   }
   if (per_rank_stats) for (size_t i = 0; i < n; ++i) per_rank_stats[i] = m->ranks[i].stats;
@@ -311,4 +318,35 @@ extern "C" int rtmi_multi_render(rtmi_multi* m, const rtmi_camera* cam, const rt
     *stats = total;
   }
   return RTMI_OK;
+}
+
+int check_multi_args(const rtmi_multi* m, const rtmi_camera* cam, const rtmi_render_params* params, uint32_t partition, const void* rgb8,
+                     const void* xyz) {
+  if (!m || !cam || !params) return fail(RTMI_BAD_ARG, "NULL argument");
+  if (!rgb8 && !xyz) return fail(RTMI_BAD_ARG, "no output buffer");
+  if (partition != RTMI_PARTITION_SAMPLES && partition != RTMI_PARTITION_TILES) return fail(RTMI_BAD_ARG, "unknown partition %u", partition);
+  if (params->sample_end || params->sample_begin || params->tile_world || params->tile_rank)
+    return fail(RTMI_BAD_ARG, "the partition fields of rtmi_render_params must be 0: the multi-device entry points set them per device");
+  if (cam->width == 0 || cam->height == 0) return fail(RTMI_BAD_ARG, "camera resolution %ux%u", cam->width, cam->height);
+  if (params->spp == 0) return fail(RTMI_BAD_ARG, "spp is 0");
+  return RTMI_OK;
+}
+
+}  // namespace
+
+extern "C" int rtmi_multi_render(rtmi_multi* m, const rtmi_camera* cam, const rtmi_render_params* params, uint32_t partition,
+                                 uint8_t* host_rgb8, float* host_xyz, rtmi_stats* stats, rtmi_stats* per_rank_stats) {
+  if (int rc = check_multi_args(m, cam, params, partition, host_rgb8, host_xyz)) return rc;
+  return render_samples(m, cam, params, partition, 0, params->spp, true, params->spp, host_rgb8, host_xyz, stats, per_rank_stats);
+}
+
+extern "C" int rtmi_multi_render_pass(rtmi_multi* m, const rtmi_camera* cam, const rtmi_render_params* params, uint32_t partition,
+                                      uint32_t pass, uint32_t n_passes, uint8_t* host_rgb8, float* host_xyz, rtmi_stats* stats) {
+  if (int rc = check_multi_args(m, cam, params, partition, host_rgb8, host_xyz)) return rc;
+  if (n_passes == 0 || pass >= n_passes || n_passes > params->spp)
+    return fail(RTMI_BAD_ARG, "pass %u of %u over %u samples", pass, n_passes, params->spp);
+  // balanced contiguous sample ranges, like the ranks' own
+  const uint32_t base = params->spp / n_passes, extra = params->spp % n_passes;
+  const uint32_t begin = pass * base + std::min(pass, extra), end = begin + base + (pass < extra ? 1u : 0u);
+  return render_samples(m, cam, params, partition, begin, end, pass == 0, end, host_rgb8, host_xyz, stats, nullptr);
 }

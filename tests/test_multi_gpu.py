@@ -74,3 +74,29 @@ def test_rccl_binding_with_one_rank(monkeypatch):
     img, xyz, st, _ = m.render(cam, p, L.PARTITION_SAMPLES)
     assert (img == ref8).all() and (xyz.view(np.uint32) == ref_xyz.view(np.uint32)).all() and st["segments"] == ref_st["segments"]
     m.close()
+
+
+def test_progressive_passes_add_up_to_the_single_render():
+    """k passes of spp / k samples: every pass returns the image of the samples so far (= a render of that many
+    samples), and the last one the full render -- bit for bit under the tile partition."""
+    from raytracing_amd import api, _lib as L
+    kw = dict(width=160, height=90)
+    b, _ = scenes.scene1(from_rgb=None, **kw)
+    spp = 7
+    cam, (full8, full_xyz, full_st) = _single(scenes.scene1, api.render_params(O.INT_RANDOM_WALK, 10, spp, seed=2), **kw)
+    _, (first8, first_xyz, _) = _single(scenes.scene1, api.render_params(O.INT_RANDOM_WALK, 10, 3, seed=2), **kw)
+    m = api.MultiScene([0, 0], *b.arrays(), max_batch_paths=1 << 22)
+    p = api.render_params(O.INT_RANDOM_WALK, 10, spp, seed=2)
+    segments = 0
+    for k in range(3):          # 3 + 2 + 2 samples
+        img, xyz, st = m.render_pass(cam, p, L.PARTITION_TILES, k, 3)
+        segments += st["segments"]
+        if k == 0:              # the first pass is the image of samples 0..2
+            assert (img == first8).all() and (xyz.view(np.uint32) == first_xyz.view(np.uint32)).all()
+    assert (img == full8).all() and (xyz.view(np.uint32) == full_xyz.view(np.uint32)).all() and segments == full_st["segments"]
+    for k in range(2):
+        img, xyz, st = m.render_pass(cam, p, L.PARTITION_SAMPLES, k, 2)
+    assert np.abs(xyz - full_xyz).max() <= 4e-7 * max(1.0, float(np.abs(full_xyz).max())) and (img == full8).mean() >= 0.999
+    with pytest.raises(L.RtmiError):
+        m.render_pass(cam, p, L.PARTITION_TILES, 3, 3)
+    m.close()
