@@ -2,6 +2,15 @@
 //! Written without a Rust toolchain at hand (never compiled); it shows where each field of the
 //! reference's types goes. Register it in `enum Integrator` (src/integrators/integrator.rs:145-151)
 //! and build it in `main` where the three CPU integrators are built (src/main.rs:74-95).
+//!
+//! What it reads from the reference's types, and where that comes from:
+//!   exists today          Triangle::vértice(i) (src/shapes/triangle.rs:59), ShapeOperations::material()
+//!                         (src/shapes/shape.rs:13), Camera::width()/height() (src/camera.rs:63-69), the public fields
+//!                         of Material (src/material.rs:12-23), Rectangle's public tuple fields (src/geometry/mod.rs:12)
+//!   added by the patch    Scene::shapes(), Camera::focus()/screen(), Sphere::local_to_world()/radius(),
+//!   reference_accessors.patch   ModelObj::triangles(), CoefficientSpectrum::coefficients()
+//! The render goes through rtmi_multi_*: every GPU of the node (RTMI_DEVICES=0,1,.. or all visible ones), the scene
+//! replicated, tiles shared out as src/integrators/integrator.rs:39-50 numbers them, one RCCL reduce at the end.
 use super::integrator::SamplerIntegrator;
 use crate::{camera::Camera, geometry::Ray, material::{Material, Type}, scene::Scene, shapes::shape::Shape,
             spectrum::SampledSpectrum};
@@ -71,12 +80,12 @@ impl SamplerIntegrator for GpuIntegrator {
                 }
                 Shape::Triangle(t) => {
                     objects.push(rtmi_object { kind: RTMI_OBJ_TRIANGLE, first: triangles.len() as u32, count: 1, material });
-                    triangles.push(tri(t.vertices()));
+                    triangles.push(tri(t));
                 }
                 Shape::ModelObj(m) => {
                     // file order matters: the reference returns the first triangle in this order that the ray hits
                     objects.push(rtmi_object { kind: RTMI_OBJ_MODEL, first: triangles.len() as u32, count: m.triangles().len() as u32, material });
-                    triangles.extend(m.triangles().iter().map(|t| tri(t.vertices())));
+                    triangles.extend(m.triangles().iter().map(tri));
                 }
                 _ => anyhow::bail!("shape kind not carried by rtmi"),
             }
@@ -86,22 +95,26 @@ impl SamplerIntegrator for GpuIntegrator {
             spheres: spheres.as_ptr(), n_spheres: spheres.len() as u32,
             triangles: triangles.as_ptr(), n_triangles: triangles.len() as u32,
             materials: materials.as_ptr(), n_materials: materials.len() as u32,
-            hit_rule: RTMI_HIT_FIRST_INDEX, reserved: 0,
+            hit_rule: RTMI_HIT_FIRST_INDEX, flags: 0,
         };
-        let (w, h) = self.camera.resolution();
+        let (w, h) = (self.camera.width() as usize, self.camera.height() as usize);
         let screen = self.camera.screen();   // (p1 top-left, p2 top-right, p3 bottom-left, p4 bottom-right), src/camera.rs:4-9
-        let cam = rtmi_camera { focus: xyz(self.camera.focus()), p1: xyz(&screen.0), p2: xyz(&screen.1), p3: xyz(&screen.2),
+        let cam = rtmi_camera { focus: xyz(&self.camera.focus()), p1: xyz(&screen.0), p2: xyz(&screen.1), p3: xyz(&screen.2),
                                 p4: xyz(&screen.3), width: w as u32, height: h as u32 };
         let params = rtmi_render_params { integrator: self.kind, max_depth: self.depth as u32, spp: self.iterations as u32,
                                           seed: 0, ..Default::default() };
         let mut rgb8 = vec![0u8; w * h * 3];
+        // RTMI_DEVICES=0,1,2,3 picks the GPUs; default: device 0 only
+        let devices: Vec<i32> = std::env::var("RTMI_DEVICES").ok()
+            .map(|v| v.split(',').filter_map(|t| t.trim().parse().ok()).collect()).filter(|v: &Vec<i32>| !v.is_empty())
+            .unwrap_or_else(|| vec![0]);
         unsafe {
-            let (mut ctx, mut scene) = (ptr::null_mut(), ptr::null_mut());
-            check(rtmi_ctx_create(-1, 0, &mut ctx))?;
-            let result = check(rtmi_scene_create(ctx, &desc, &mut scene))
-                .and_then(|_| check(rtmi_render(scene, &cam, &params, rgb8.as_mut_ptr(), ptr::null_mut(), ptr::null_mut())));
-            rtmi_scene_destroy(scene);
-            rtmi_ctx_destroy(ctx);
+            let mut multi = ptr::null_mut();
+            check(rtmi_multi_create(devices.as_ptr(), devices.len() as i32, 0, &desc, &mut multi))?;
+            // tiles: bit-identical to one GPU; RTMI_PARTITION_SAMPLES balances better when spp >= number of GPUs
+            let result = check(rtmi_multi_render(multi, &cam, &params, RTMI_PARTITION_TILES, rgb8.as_mut_ptr(), ptr::null_mut(),
+                                                 ptr::null_mut(), ptr::null_mut()));
+            rtmi_multi_destroy(multi);
             result?;
         }
         // row-major, y = 0 at the top: the layout SamplerIntegrator::render fills (src/integrators/integrator.rs:110-112)
@@ -110,6 +123,9 @@ impl SamplerIntegrator for GpuIntegrator {
 }
 
 fn xyz(p: &crate::geometry::Point) -> [f64; 3] { [p.x, p.y, p.z] }
-fn tri(v: &[crate::geometry::Point; 3]) -> rtmi_triangle {
-    rtmi_triangle { v: [v[0].x, v[0].y, v[0].z, v[1].x, v[1].y, v[1].z, v[2].x, v[2].y, v[2].z] }
+fn tri(t: &crate::shapes::Triangle) -> rtmi_triangle {
+    // the loaders give every triangle the identity local->world map (src/scene_config.rs:189, src/shapes/model_obj.rs:54),
+    // so the stored vertices are world-space
+    let (a, b, c) = (t.vértice(0), t.vértice(1), t.vértice(2));
+    rtmi_triangle { v: [a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z] }
 }

@@ -14,6 +14,8 @@ pub const RTMI_NO_DEVICE: c_int = -2;
 pub const RTMI_OOM: c_int = -3;
 pub const RTMI_HIP_ERROR: c_int = -4;
 pub const RTMI_UNSUPPORTED: c_int = -5;
+pub const RTMI_RCCL_ERROR: c_int = -6;
+pub const RTMI_INTERNAL: c_int = -7;
 
 pub const RTMI_OBJ_SPHERE: u32 = 0;
 pub const RTMI_OBJ_TRIANGLE: u32 = 1;
@@ -36,6 +38,9 @@ pub const RTMI_SPEC_REFLECTANCE: c_int = 0;
 pub const RTMI_SPEC_ILLUMINANT: c_int = 1;
 pub const RTMI_FLAG_TIME_KERNELS: u32 = 1;
 pub const RTMI_FLAG_COUNT_TRAVERSAL: u32 = 2;
+pub const RTMI_SCENE_GPU_BVH: u32 = 1;
+pub const RTMI_PARTITION_SAMPLES: u32 = 0;
+pub const RTMI_PARTITION_TILES: u32 = 1;
 
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct rtmi_ray { pub o: [f64; 3], pub d: [f64; 3] }
@@ -71,7 +76,7 @@ pub struct rtmi_scene_desc {
     pub triangles: *const rtmi_triangle, pub n_triangles: u32,
     pub materials: *const rtmi_material, pub n_materials: u32,
     pub hit_rule: u32,
-    pub reserved: u32,
+    pub flags: u32,
 }
 
 #[repr(C)] #[derive(Clone, Copy, Default)]
@@ -103,10 +108,15 @@ pub struct rtmi_stats {
 pub struct rtmi_scene_info {
     pub n_nodes: u32, pub max_depth: u32, pub n_mesh_triangles: u32, pub n_spectra: u32,
     pub node_bytes: u64, pub triangle_bytes: u64,
+    pub bvh_build_ms: f64, pub bvh_device_ms: f64, pub upload_ms: f64,
 }
+
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct rtmi_multi_info_t { pub n_ranks: u32, pub uses_rccl: u32, pub rccl_library: [c_char; 240] }
 
 pub enum rtmi_ctx {}
 pub enum rtmi_scene {}
+pub enum rtmi_multi {}
 
 extern "C" {
     pub fn rtmi_ctx_create(device_id: c_int, max_batch_paths: u64, out: *mut *mut rtmi_ctx) -> c_int;
@@ -142,4 +152,15 @@ extern "C" {
     pub fn rtmi_render_collect_stats(scene: *mut rtmi_scene, stream: *mut c_void, stats: *mut rtmi_stats) -> c_int;
     pub fn rtmi_tonemap(ctx: *mut rtmi_ctx, dev_xyz_sum: *const f32, spp: u32, width: u32, height: u32,
                         dev_rgb8: *mut u8, stream: *mut c_void) -> c_int;
+    pub fn rtmi_render_accumulate_noalloc(scene: *mut rtmi_scene, cam: *const rtmi_camera, params: *const rtmi_render_params,
+                                          dev_xyz_sum: *mut f32, stream: *mut c_void) -> c_int;
+
+    pub fn rtmi_multi_create(device_ids: *const c_int, n: c_int, max_batch_paths: u64, desc: *const rtmi_scene_desc,
+                             out: *mut *mut rtmi_multi) -> c_int;
+    pub fn rtmi_multi_destroy(multi: *mut rtmi_multi);
+    pub fn rtmi_multi_info(multi: *const rtmi_multi, out: *mut rtmi_multi_info_t) -> c_int;
+    pub fn rtmi_multi_render(multi: *mut rtmi_multi, cam: *const rtmi_camera, params: *const rtmi_render_params, partition: u32,
+                             host_rgb8: *mut u8, host_xyz: *mut f32, stats: *mut rtmi_stats, per_rank_stats: *mut rtmi_stats) -> c_int;
+    pub fn rtmi_multi_render_pass(multi: *mut rtmi_multi, cam: *const rtmi_camera, params: *const rtmi_render_params, partition: u32,
+                                  pass: u32, n_passes: u32, host_rgb8: *mut u8, host_xyz: *mut f32, stats: *mut rtmi_stats) -> c_int;
 }
