@@ -67,32 +67,45 @@ def build_scene(ctx, w, hit_rule, from_rgb=None, library=True, scene_flags=0, **
     return builder, cam_args
 
 
-def cpu_baseline(w, hit_rule, threads, target_seconds=12.0):
+def cpu_baseline(w, hit_rule, threads, target_seconds=10.0):
     """The CPU oracle (linear scans over objects and triangles: the reference's algorithm) on a bounded sample of the
     same workload, on this machine's host cores. The sample keeps the camera and the scene and cuts samples per pixel
     first, then (for the million-triangle mesh, where one segment costs a million triangle tests) the resolution: the
-    same field of view through fewer pixels is a uniform subsample of the image's paths."""
+    same field of view through fewer pixels is a uniform subsample of the image's paths.
+    Two shorter legs beside it: the same port on one thread, and the same port with a median-split BVH over each mesh
+    (not the reference's algorithm -- the "fair" CPU figure: same results, same kind of acceleration as the GPU path)."""
     import _oracle as O
     mesh = w["recipe"] == "synthetic_mesh_scene"
     div = 60 if mesh else 1
     override = dict(width=w["width"] // div, height=w["height"] // div) if div > 1 else {}
     builder, cam_args = build_scene(None, w, hit_rule, from_rgb=O.from_rgb, library=False, **override)
-    scene = O.Scene(*builder.arrays(), hit_rule=hit_rule)
     cam = O.camera(*cam_args)
-    spp = 1
-    total_seg, total_s, done = 0, 0.0, 0
-    # grow the sample until it has run for about target_seconds (each leg renders samples [done, done + spp))
-    while done < w["spp"] and total_s < target_seconds:
-        spp = min(spp, w["spp"] - done)
-        _, _, _, st = scene.render(cam, O.INT_RANDOM_WALK, w["depth"], w["spp"], seed=0, sample_range=(done, done + spp),
-                                   threads=threads, want_lin=False)
-        total_seg += st.segments; total_s += st.seconds; done += spp
-        if st.seconds > 0:
-            spp = max(1, min(int(spp * min(4.0, 0.5 * target_seconds / st.seconds)), 64))
-    what = "same scene and camera%s, samples [0,%d) of %d per pixel: %d segments in %.1f s" % (
-        " through %dx%d pixels (1/%d of the image's)" % (cam.width, cam.height, div * div) if div > 1 else "", done, w["spp"],
-        total_seg, total_s)
-    return total_seg / total_s / 1e6, what
+    where = " through %dx%d pixels (1/%d of the image's)" % (cam.width, cam.height, div * div) if div > 1 else ""
+
+    def leg(scene, n_threads, seconds, first_spp=1):
+        spp, total_seg, total_s, done = first_spp, 0, 0.0, 0
+        # grow the sample until it has run for about `seconds` (each round renders samples [done, done + spp))
+        while done < w["spp"] and total_s < seconds:
+            spp = min(spp, w["spp"] - done)
+            _, _, _, st = scene.render(cam, O.INT_RANDOM_WALK, w["depth"], w["spp"], seed=0, sample_range=(done, done + spp),
+                                       threads=n_threads, want_lin=False)
+            total_seg += st.segments; total_s += st.seconds; done += spp
+            if st.seconds > 0:
+                spp = max(1, min(int(spp * min(4.0, 0.5 * seconds / st.seconds)), 64))
+        return total_seg / total_s / 1e6, "same scene and camera%s, samples [0,%d) of %d per pixel: %d segments in %.1f s" % (
+            where, done, w["spp"], total_seg, total_s)
+
+    scene = O.Scene(*builder.arrays(), hit_rule=hit_rule)
+    value, what = leg(scene, threads, target_seconds)
+    extra = {}
+    if not mesh:   # one thread of the linear scan over a million triangles would take minutes for a handful of paths
+        v1, what1 = leg(scene, 1, 0.3 * target_seconds)
+        extra["one_thread"] = {"value": v1, "unit": "Mseg/s", "cores": 1, "sample": what1}
+    scene.enable_bvh()
+    vb, whatb = leg(scene, threads, 0.4 * target_seconds, first_spp=1 if not mesh else 4)
+    extra["with_bvh"] = {"value": vb, "unit": "Mseg/s", "cores": threads, "sample": whatb,
+                         "note": "not the reference's algorithm: the port with a median-split BVH per mesh, same results"}
+    return value, what, extra
 
 
 # ------------------------------------------------------------------------------------------- launcher
@@ -282,9 +295,10 @@ def main():
         share = int(os.environ.get("OMP_NUM_THREADS", "0")) or cores     # the box's CPU share when it is smaller than the machine
         threads = args.cpu_threads or max(1, min(cores, share))
         rule0 = L0.HIT_FIRST_INDEX if args.rule == "first_index" else L0.HIT_NEAREST
-        v, what = cpu_baseline(w, rule0, threads)
+        v, what, extra = cpu_baseline(w, rule0, threads)
         cpu = {"value": v, "unit": "Mseg/s", "cores": threads, "kind": "port", "sample": what,
                "host_cores_visible": os.cpu_count(), "cores_usable": max(1, min(cores, share))}
+        cpu.update(extra)
 
     import torch
     import torch.distributed as dist

@@ -546,9 +546,17 @@ void ref_uniform_pair(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t b
 
 /* ---------------------------------------------------------------- scene (scene.rs, model_obj.rs) */
 
+/* Optional median-split BVH over a model's triangles. It is NOT part of the restatement of the reference (which scans
+ * every triangle, model_obj.rs:80-84) and is never used for parity: it exists so that a CPU baseline with the same
+ * kind of acceleration the GPU path uses can be timed beside the faithful linear scan (ref_scene_enable_bvh). It
+ * returns the linear scan's results: boxes are padded, distance never prunes under the first-index rule. */
+typedef struct { double lo[3], hi[3]; uint32_t left, right, first, count, min_index; } cpu_bvh_node;
+typedef struct { cpu_bvh_node* nodes; uint32_t n_nodes; uint32_t* order; } cpu_bvh;
+
 typedef struct {
   ref_affine l2w, w2l;  /* spheres and top-level triangles */
   v3 bmin, bmax;        /* models: box grown from the origin point (model_obj.rs:62-66) */
+  cpu_bvh bvh;          /* models, only after ref_scene_enable_bvh */
 } obj_aux;
 
 struct ref_scene {
@@ -560,6 +568,7 @@ struct ref_scene {
   obj_aux* aux;
   uint32_t hit_rule;
   ref_affine identity;
+  int use_bvh;
 };
 
 static void* dup_mem(const void* p, size_t n) {
@@ -609,6 +618,7 @@ ref_scene* ref_scene_create(const ref_scene_desc* d) {
 
 void ref_scene_destroy(ref_scene* s) {
   if (!s) return;
+  for (uint32_t i = 0; i < s->n_objects; ++i) { free(s->aux[i].bvh.nodes); free(s->aux[i].bvh.order); }
   free(s->objects); free(s->spheres); free(s->triangles); free(s->materials); free(s->tri_normals); free(s->aux);
   free(s);
 }
@@ -620,9 +630,122 @@ void ref_scene_model_bounds(const ref_scene* s, uint32_t obj, double bmin[3], do
 /* src/shapes/model_obj.rs:77-87: box prefilter, then the FIRST triangle in file order that
  * reports a hit (not the nearest). REF_HIT_NEAREST is the physically correct alternative:
  * smallest t, ties to the smaller index. */
+/* ---- the optional CPU BVH (not the reference's algorithm; see cpu_bvh above) ---- */
+typedef struct { const ref_triangle* tris; double (*cent)[3]; uint32_t* order; cpu_bvh_node* nodes; uint32_t n_nodes; double pad; } bvh_builder;
+
+static int cmp_axis;
+static double (*cmp_cent)[3];
+static int cmp_order(const void* a, const void* b) {
+  double x = cmp_cent[*(const uint32_t*)a][cmp_axis], y = cmp_cent[*(const uint32_t*)b][cmp_axis];
+  return x < y ? -1 : (x > y ? 1 : (*(const uint32_t*)a < *(const uint32_t*)b ? -1 : 1));
+}
+
+static uint32_t bvh_build_range(bvh_builder* b, uint32_t first, uint32_t count) {
+  uint32_t id = b->n_nodes++;
+  cpu_bvh_node* n = &b->nodes[id];
+  for (int k = 0; k < 3; ++k) { n->lo[k] = INFINITY; n->hi[k] = -INFINITY; }
+  n->min_index = 0xFFFFFFFFu;
+  double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (uint32_t i = first; i < first + count; ++i) {
+    uint32_t t = b->order[i];
+    if (t < n->min_index) n->min_index = t;
+    for (int v = 0; v < 3; ++v) for (int k = 0; k < 3; ++k) {
+      double x = b->tris[t].v[v * 3 + k];
+      if (x - b->pad < n->lo[k]) n->lo[k] = x - b->pad;
+      if (x + b->pad > n->hi[k]) n->hi[k] = x + b->pad;
+    }
+    for (int k = 0; k < 3; ++k) { if (b->cent[t][k] < clo[k]) clo[k] = b->cent[t][k]; if (b->cent[t][k] > chi[k]) chi[k] = b->cent[t][k]; }
+  }
+  n->first = first; n->count = count; n->left = n->right = 0;
+  if (count <= 4) return id;
+  int axis = 0;
+  for (int k = 1; k < 3; ++k) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+  cmp_axis = axis; cmp_cent = b->cent;
+  qsort(b->order + first, count, sizeof(uint32_t), cmp_order);
+  uint32_t half = count / 2;
+  uint32_t l = bvh_build_range(b, first, half);
+  uint32_t r = bvh_build_range(b, first + half, count - half);
+  n = &b->nodes[id];
+  n->left = l; n->right = r; n->count = 0;
+  return id;
+}
+
+void ref_scene_enable_bvh(ref_scene* s, int on) {
+  s->use_bvh = on;
+  if (!on) return;
+  for (uint32_t i = 0; i < s->n_objects; ++i) {
+    const ref_object* o = &s->objects[i];
+    obj_aux* a = &s->aux[i];
+    if (o->kind != REF_OBJ_MODEL || a->bvh.nodes || o->count == 0) continue;
+    bvh_builder b;
+    b.tris = s->triangles + o->first;
+    b.cent = (double(*)[3])malloc(sizeof(double[3]) * o->count);
+    b.order = (uint32_t*)malloc(sizeof(uint32_t) * o->count);
+    b.nodes = (cpu_bvh_node*)malloc(sizeof(cpu_bvh_node) * 2 * (size_t)o->count);
+    b.n_nodes = 0;
+    double ext = 0.0;
+    for (uint32_t t = 0; t < o->count; ++t) {
+      b.order[t] = t;
+      for (int k = 0; k < 3; ++k) {
+        b.cent[t][k] = (b.tris[t].v[k] + b.tris[t].v[3 + k] + b.tris[t].v[6 + k]) / 3.0;
+        for (int v = 0; v < 3; ++v) if (fabs(b.tris[t].v[v * 3 + k]) > ext) ext = fabs(b.tris[t].v[v * 3 + k]);
+      }
+    }
+    b.pad = ext * 1e-9 + 1e-30;   /* Moller-Trumbore accepts points a few ulps outside the exact triangle */
+    bvh_build_range(&b, 0, o->count);
+    free(b.cent);
+    a->bvh.nodes = b.nodes; a->bvh.n_nodes = b.n_nodes; a->bvh.order = b.order;
+  }
+}
+
+static inline int bvh_box_hit(const cpu_bvh_node* n, const double o[3], const double inv[3], double tmax) {
+  double t0 = 0.0, t1 = tmax;
+  for (int k = 0; k < 3; ++k) {
+    double a = (n->lo[k] - o[k]) * inv[k], b = (n->hi[k] - o[k]) * inv[k];
+    double lo = a < b ? a : b, hi = a < b ? b : a;
+    if (lo != lo || hi != hi) continue;           /* 0 * inf: the ray runs inside this slab's plane; do not reject */
+    if (lo > t0) t0 = lo;
+    if (hi < t1) t1 = hi;
+  }
+  return t0 <= t1 * (1.0 + 1e-12) + 1e-300;
+}
+
+static int model_hit_bvh(const ref_scene* s, const ref_object* o, const obj_aux* a, rayi ray, hiti* out) {
+  const cpu_bvh* bv = &a->bvh;
+  const double org[3] = {ray.o.x, ray.o.y, ray.o.z};
+  const double inv[3] = {1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z};
+  uint32_t stack[128];
+  int sp = 0, found = 0;
+  uint32_t best_index = 0xFFFFFFFFu;
+  stack[sp++] = 0;
+  while (sp) {
+    const cpu_bvh_node* n = &bv->nodes[stack[--sp]];
+    if (s->hit_rule == REF_HIT_FIRST_INDEX && n->min_index >= best_index) continue;
+    /* the box test is a necessary condition only; slack on tmax because triangle t and box t round differently */
+    double tmax = (s->hit_rule == REF_HIT_NEAREST && found) ? out->t * (1.0 + 1e-9) + 1e-9 : INFINITY;
+    if (!bvh_box_hit(n, org, inv, tmax)) continue;
+    if (n->count) {
+      for (uint32_t i = n->first; i < n->first + n->count; ++i) {
+        uint32_t k = bv->order[i];
+        if (s->hit_rule == REF_HIT_FIRST_INDEX && k >= best_index) continue;
+        hiti h;
+        if (triangle_hit(s->triangles[o->first + k].v, s->tri_normals[o->first + k], &s->identity, &s->identity, ray, &h)) {
+          h.prim = k;
+          if (s->hit_rule == REF_HIT_FIRST_INDEX) { *out = h; best_index = k; found = 1; }
+          else if (!found || h.t < out->t || (h.t == out->t && k < out->prim)) { *out = h; found = 1; }
+        }
+      }
+    } else if (sp + 2 <= 128) {
+      stack[sp++] = n->right; stack[sp++] = n->left;
+    }
+  }
+  return found;
+}
+
 static inline int model_hit(const ref_scene* s, const ref_object* o, const obj_aux* a, rayi ray, hiti* out) {
   double tbox;
   if (!aabb_hit(a->bmin, a->bmax, ray, &tbox)) return 0;
+  if (s->use_bvh && a->bvh.nodes) return model_hit_bvh(s, o, a, ray, out);
   int found = 0;
   for (uint32_t k = 0; k < o->count; ++k) {
     hiti h;

@@ -136,6 +136,10 @@ void ref_uniform_pair(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t b
 /* scene + integrators (src/scene.rs, src/integrators/) */
 ref_scene* ref_scene_create(const ref_scene_desc* desc);
 void ref_scene_destroy(ref_scene* s);
+/* NOT the reference's algorithm: switches the models' triangle scan to a median-split BVH that returns the same hits,
+ * so that an accelerated CPU baseline can be timed beside the faithful linear scan. Parity tests never enable it
+ * (except the one that checks it against the linear scan). */
+void ref_scene_enable_bvh(ref_scene* s, int on);
 void ref_scene_model_bounds(const ref_scene* s, uint32_t obj, double bmin[3], double bmax[3]);
 int  ref_scene_intersect(const ref_scene* s, const ref_ray* r, ref_hit* out);
 void ref_intersect_batch(const ref_scene* s, const ref_ray* rays, size_t n, ref_hit* out, int threads);

@@ -11,7 +11,8 @@ import numpy as np
 
 from . import _lib as L
 
-GOLDEN_MESHES = Path(__file__).resolve().parent.parent / "tests" / "golden" / "meshes.npz"
+# geometry of the two stock meshes (cube room, Suzanne) as polygon soups; written by tests/golden/make_mesh_fixtures.py
+GOLDEN_MESHES = Path(__file__).resolve().parent / "data" / "meshes.npz"
 
 
 def fan_triangulate(vertices, face_index, face_offsets, origin="last"):

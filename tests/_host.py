@@ -72,9 +72,9 @@ class LoadedScene:
     __del__ = close
 
 
-def write_obj(path, mesh_name, mtl_name, golden="meshes.npz"):
+def write_obj(path, mesh_name, mtl_name):
     """Writes a golden mesh back out as an OBJ file with polygon faces and v/vt/vn style corners."""
-    z = np.load(ROOT / "tests" / "golden" / golden)
+    z = np.load(ROOT / "raytracing_amd" / "data" / "meshes.npz")
     v, idx, offs = z[mesh_name + "_vertices"], z[mesh_name + "_face_index"], z[mesh_name + "_face_offsets"]
     lines = ["# written by tests/_host.py", "mtllib %s" % mtl_name, "o Mesh"]
     lines += ["v %r %r %r" % tuple(float(c) for c in p) for p in v]

@@ -126,6 +126,7 @@ def lib():
     L.ref_scene_create.restype = C.c_void_p
     L.ref_scene_create.argtypes = [C.POINTER(SceneDesc)]
     L.ref_scene_destroy.argtypes = [C.c_void_p]
+    L.ref_scene_enable_bvh.argtypes = [C.c_void_p, C.c_int]
     L.ref_scene_model_bounds.argtypes = [C.c_void_p, C.c_uint32, d3, d3]
     L.ref_scene_intersect.argtypes = [C.c_void_p, C.POINTER(Ray), C.POINTER(Hit)]
     L.ref_intersect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
@@ -186,6 +187,10 @@ class Scene:
         if getattr(self, "handle", None):
             lib().ref_scene_destroy(self.handle)
             self.handle = None
+
+    def enable_bvh(self, on=True):
+        """Not the reference's algorithm: an accelerated CPU baseline with the linear scan's results (timing only)."""
+        lib().ref_scene_enable_bvh(self.handle, 1 if on else 0)
 
     def intersect_batch(self, rays, threads=None):
         rays = np.ascontiguousarray(rays, dtype=RAY_DT)

@@ -3,7 +3,7 @@
 
 Reads /root/reference/{cubo,mono}.obj (positions and polygon faces only -- the reference's
 loader ignores normals and texture coordinates, src/shapes/model_obj.rs:40-53) and writes
-tests/golden/meshes.npz with, per mesh, the vertex array (f64) and the polygon faces as a flat
+raytracing_amd/data/meshes.npz (the package ships it: the benchmark scenes use it) with, per mesh, the vertex array (f64) and the polygon faces as a flat
 0-based index array plus per-face offsets. Polygons are kept as polygons so that either fan
 triangulation can be derived from the fixture. Run once in the build container; the GPU box
 has no /root/reference and only ever reads the .npz.
@@ -14,7 +14,7 @@ from pathlib import Path
 import numpy as np
 
 REF = Path(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
-OUT = Path(__file__).resolve().parent / "meshes.npz"
+OUT = Path(__file__).resolve().parent.parent.parent / "raytracing_amd" / "data" / "meshes.npz"
 
 
 def read_obj(path):

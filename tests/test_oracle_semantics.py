@@ -215,3 +215,20 @@ def test_pixel_jitter_covers_the_pixel(oracle):
         u.append((out[0], out[1]))
     u = np.array(u)
     assert u.min() >= 0 and u.max() < 1 and (np.abs(u.mean(axis=0) - 0.5) < 0.05).all()
+
+
+def test_optional_cpu_bvh_returns_the_linear_scan(oracle):
+    """ref_scene_enable_bvh is not part of the restatement (the reference scans every triangle); it only serves the
+    accelerated CPU baseline. It must not change a single hit or path under either rule."""
+    import numpy as np
+    import _scenes as S
+    O = oracle
+    for rule in (O.HIT_FIRST_INDEX, O.HIT_NEAREST):
+        plain, cam, _ = S.oracle_scene(S.multi_mesh_scene, hit_rule=rule, width=96, height=54)
+        fast, _, _ = S.oracle_scene(S.multi_mesh_scene, hit_rule=rule, width=96, height=54)
+        fast.enable_bvh()
+        rays = np.concatenate([S.primary_rays(cam), S.random_rays(6000, 3, center=(0.5, 0.0, 1.0), radius=5.0)])
+        assert plain.intersect_batch(rays).tobytes() == fast.intersect_batch(rays).tobytes()
+        a = plain.render(cam, O.INT_RANDOM_WALK, 8, 2, seed=3)
+        b = fast.render(cam, O.INT_RANDOM_WALK, 8, 2, seed=3)
+        assert (a[0] == b[0]).all() and a[3].segments == b[3].segments

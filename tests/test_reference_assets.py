@@ -1,6 +1,6 @@
 """The C++ loaders on the reference's own asset files (scene.toml, scene2.toml, scene3.toml, cubo.obj/.mtl,
 mono.obj/.mtl), read where they lie in the build container. The GPU box has no /root/reference: there these tests are
-skipped and the committed fixtures (tests/golden/meshes.npz, the recipes in raytracing_amd/scenes.py) stand in, which is
+skipped and the committed fixtures (raytracing_amd/data/meshes.npz, the recipes in raytracing_amd/scenes.py) stand in, which is
 why this file checks that those stand-ins say exactly what the files say. Nothing is copied: the files are only parsed."""
 import importlib.util
 from pathlib import Path
@@ -33,7 +33,7 @@ def test_mesh_fixture_regenerates_identically(tmp_path):
     spec = importlib.util.spec_from_file_location("make_mesh_fixtures", Path(__file__).resolve().parent / "golden" / "make_mesh_fixtures.py")
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    committed = np.load(Path(__file__).resolve().parent / "golden" / "meshes.npz")
+    committed = np.load(Path(__file__).resolve().parent.parent / "raytracing_amd" / "data" / "meshes.npz")
     for name, fname in (("cubo", "cubo.obj"), ("mono", "mono.obj")):
         v, i, o = mod.read_obj(REF / fname)
         assert (committed[name + "_vertices"] == v).all() and committed[name + "_vertices"].dtype == v.dtype
