@@ -870,33 +870,62 @@ __device__ __forceinline__ Shaded shade_hit(const DevScene& sc, const BatchDesc&
   return r;
 }
 
-// Emitter hits of a wave go to the emit queue: one ballot, one atomic on the fill counter of the
-// region this chunk feeds. A wave that finds its region full marks what it reserved as unused and
-// forms its spectra in place instead. Must be reached by all lanes of the wave.
-__device__ __forceinline__ void append_emit(const DevScene& sc, const TraceOutputs& o, uint32_t chunk, bool deep, bool emits,
-                                            uint32_t emit_info, uint32_t slot, const Chain& chain) {
-  const unsigned long long emask = __ballot(emits);
-  if (!emask) return;
+// What a wave appends at the end of a bounce goes to up to three sharded lists (emitter hits for emit_kernel, and
+// the continuing paths in one or two classes). Their places are reserved with ONE atomic instruction: lane j of the
+// wave adds list j's count to that list's fill counter of region chunk % kShards, so the wave waits for one round
+// trip to the L2 instead of three in a row. Must be reached by all lanes of the wave.
+struct Appends {
+  unsigned long long emit_mask, first_mask, second_mask;   // the lanes that append to each list
+  uint32_t emit_start, first_start, second_start;          // where the wave's run begins inside the region
+};
+
+__device__ __forceinline__ Appends reserve_appends(uint32_t* emit_counts, uint32_t* first_counts, uint32_t* second_counts,
+                                                   uint32_t region_entries, uint32_t chunk, bool emits, bool first, bool second) {
+  Appends a;
+  a.emit_mask = __ballot(emits); a.first_mask = __ballot(first); a.second_mask = __ballot(second);
+  a.emit_start = a.first_start = a.second_start = 0;
+  if (!(a.emit_mask | a.first_mask | a.second_mask)) return a;
   const uint32_t lane = __lane_id();
-  const uint32_t leader = uint32_t(__ffsll((long long)emask)) - 1u;
-  const uint32_t region = chunk % kShards, want = uint32_t(__popcll(emask));
+  const unsigned long long mine = lane == 0 ? a.emit_mask : (lane == 1 ? a.first_mask : a.second_mask);
+  uint32_t* counter = (lane == 0 ? emit_counts : (lane == 1 ? first_counts : second_counts)) + (chunk % kShards) * kCountStride;
+  const uint32_t want = uint32_t(__popcll(mine));
   uint32_t start = 0;
-  if (lane == leader) start = atomicAdd(o.emit_counts + region * kCountStride, want);
-  start = __shfl(start, int(leader));
-  const uint32_t rank = uint32_t(__popcll(emask & ((1ull << lane) - 1ull)));
-  const bool fits = start + want <= o.emit_region_entries;
-  if (emits) {
-    const uint32_t at = region * o.emit_region_entries + start + rank;
-    if (fits) {
-      o.emit.slot[at] = slot; o.emit.info[at] = emit_info; o.emit.chain0[at] = chain.a;
-      if (deep) o.emit.chain1[at] = chain.b;
-    } else {
-      if (start + rank < o.emit_region_entries) o.emit.slot[at] = RT_MISS;
-      float xyz[3];
-      emit_sample(sc.spectra, emit_info & 0xFFu, chain, emit_info >> 8, xyz, o.spectra ? o.spectra + size_t(slot) * RT_NBINS : nullptr);
-      o.contrib_x[slot] = xyz[0]; o.contrib_y[slot] = xyz[1]; o.contrib_z[slot] = xyz[2];
-    }
+  if (lane < 3 && want) {
+    start = atomicAdd(counter, want);
+    // the queue regions are sized so that this cannot happen; the emit list has its own way out (emit_or_append)
+    if (lane != 0 && start + want > region_entries) counter[kOverflowWord] = 1u;
   }
+  a.emit_start = __shfl(start, 0); a.first_start = __shfl(start, 1); a.second_start = __shfl(start, 2);
+  return a;
+}
+
+__device__ __forceinline__ uint32_t rank_in(unsigned long long mask) {
+  return uint32_t(__popcll(mask & ((1ull << __lane_id()) - 1ull)));
+}
+
+// Emitter hits go to the emit queue. A wave that finds its region full marks what it reserved as unused and forms
+// its spectra in place instead.
+__device__ __forceinline__ void emit_or_append(const DevScene& sc, const TraceOutputs& o, uint32_t chunk, bool deep, const Appends& a,
+                                               bool emits, uint32_t emit_info, uint32_t slot, const Chain& chain) {
+  if (!emits) return;
+  const uint32_t want = uint32_t(__popcll(a.emit_mask)), rank = rank_in(a.emit_mask);
+  const uint32_t at = (chunk % kShards) * o.emit_region_entries + a.emit_start + rank;
+  if (a.emit_start + want <= o.emit_region_entries) {
+    o.emit.slot[at] = slot; o.emit.info[at] = emit_info; o.emit.chain0[at] = chain.a;
+    if (deep) o.emit.chain1[at] = chain.b;
+  } else {
+    if (a.emit_start + rank < o.emit_region_entries) o.emit.slot[at] = RT_MISS;
+    float xyz[3];
+    emit_sample(sc.spectra, emit_info & 0xFFu, chain, emit_info >> 8, xyz, o.spectra ? o.spectra + size_t(slot) * RT_NBINS : nullptr);
+    o.contrib_x[slot] = xyz[0]; o.contrib_y[slot] = xyz[1]; o.contrib_z[slot] = xyz[2];
+  }
+}
+
+// Position inside its region of a lane that appends to a list whose run starts at `start`; RT_MISS past the region's end,
+// so nothing is ever written outside a region.
+__device__ __forceinline__ uint32_t place_in(unsigned long long mask, uint32_t start, uint32_t region_entries) {
+  const uint32_t within = start + rank_in(mask);
+  return within < region_entries ? within : RT_MISS;
 }
 
 // Wave-level compaction of the lanes with `take` set into region chunk % kShards of a sharded
@@ -999,19 +1028,6 @@ __device__ __forceinline__ bool queue_position2(const ChunkMap& m, uint32_t regi
   return within < fill;
 }
 
-// Reserves a place for the lane's path in region chunk % kShards, in the mesh class (from the front) or the other
-// class (from the back). Both classes together receive at most the survivors of the chunks that feed the region,
-// which is what it is sized for. Must be reached by all lanes of the wave.
-__device__ __forceinline__ uint32_t reserve_by_class(uint32_t* mesh_counts, uint32_t* other_counts, uint32_t region_entries,
-                                                     uint32_t chunk, bool alive, bool meets_mesh) {
-  const uint32_t front = reserve_offset(mesh_counts, region_entries, chunk, alive && meets_mesh);
-  const uint32_t back = reserve_offset(other_counts, region_entries, chunk, alive && !meets_mesh);
-  const uint32_t within = meets_mesh ? front : back;
-  if (!alive || within == RT_MISS) return RT_MISS;
-  const uint32_t region = chunk % kShards;
-  return region * region_entries + (meets_mesh ? within : region_entries - 1u - within);
-}
-
 // ------------------------------------------------------------------------------- the fused bounce kernel
 
 // The dense kernels take their arguments as one struct and read its fields through the kernel-argument pointer
@@ -1071,9 +1087,11 @@ bounce_kernel(BounceArgs a) {
       const bool found = closest_hit<RULE, COUNT, MESH>(sc, node_words, ps.o, ps.d, stack, hit, n_nodes, n_prims);
       sh = shade_hit<EXT>(sc, b, o, found, hit, PRIMARY, ps);
     }
-    append_emit(sc, o, chunk, deep, sh.emits, sh.emit_info, ps.slot, ps.chain);
-    const uint32_t at = reserve_in_region(out_counts, region_entries, chunk, sh.alive);
-    if (at != RT_MISS) queue_store(out, at, sh.no, sh.nd, ps.pixel, ps.sample, ps.slot, ps.remaining - 1, ps.chain, deep);
+    const Appends ap3 = reserve_appends(o.emit_counts, out_counts, out_counts, region_entries, chunk, sh.emits, sh.alive, false);
+    emit_or_append(sc, o, chunk, deep, ap3, sh.emits, sh.emit_info, ps.slot, ps.chain);
+    const uint32_t within = sh.alive ? place_in(ap3.first_mask, ap3.first_start, region_entries) : RT_MISS;
+    if (within != RT_MISS)
+      queue_store(out, (chunk % kShards) * region_entries + within, sh.no, sh.nd, ps.pixel, ps.sample, ps.slot, ps.remaining - 1, ps.chain, deep);
   }
 
   if (COUNT) {
@@ -1234,9 +1252,18 @@ __device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
       const bool first_hit = b.integrator != RT_INT_RANDOM_WALK || ps.remaining == b.max_depth;
       sh = shade_hit<EXT>(sc, b, o, found, hit, first_hit, ps);
     }
-    append_emit(sc, o, chunk, deep, sh.emits, sh.emit_info, ps.slot, ps.chain);
+    // a level keeps its paths in two classes per region: those whose ray meets a mesh's box fill it from the front,
+    // the others from the back (see number_chunks2)
     const bool meets_mesh = sh.alive && meets_any_mesh(sc, sh.no, sh.nd);
-    const uint32_t at = reserve_by_class(out_counts.mesh, out_counts.other, region_entries, chunk, sh.alive, meets_mesh);
+    const Appends ap3 = reserve_appends(o.emit_counts, out_counts.mesh, out_counts.other, region_entries, chunk, sh.emits, meets_mesh,
+                                        sh.alive && !meets_mesh);
+    emit_or_append(sc, o, chunk, deep, ap3, sh.emits, sh.emit_info, ps.slot, ps.chain);
+    uint32_t at = RT_MISS;
+    if (sh.alive) {
+      const uint32_t within = meets_mesh ? place_in(ap3.first_mask, ap3.first_start, region_entries)
+                                         : place_in(ap3.second_mask, ap3.second_start, region_entries);
+      if (within != RT_MISS) at = (chunk % kShards) * region_entries + (meets_mesh ? within : region_entries - 1u - within);
+    }
     if (at != RT_MISS) {
       queue_store(out, at, sh.no, sh.nd, ps.pixel, ps.sample, ps.slot, ps.remaining - 1, ps.chain, deep);
       out.hit_obj()[at] = RT_MISS;
