@@ -1326,9 +1326,6 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
   typedef NodeFmt<FMT> F;
   extern __shared__ uint4 lds_dynamic[];
   __shared__ uint32_t s_prefix[kShards + 1];   // list entries before each region
-  uint32_t* stack32;
-  const uint4* node_words = stage_nodes<STAGED>(sc, lds_dynamic, stack32);
-  typename F::stack_t* stack = reinterpret_cast<typename F::stack_t*>(stack32 - threadIdx.x) + threadIdx.x;
   if (threadIdx.x < kShards) {
     uint32_t fill = mesh.counts[threadIdx.x * kCountStride];
     fill = fill < region_entries ? fill : region_entries;
@@ -1350,6 +1347,11 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
   uint32_t share = (total + n_waves - 1) / n_waves;
   share = share < 64u ? 64u : share;
   share = (share + 63u) & ~63u;
+  // a short list leaves the later workgroups of the grid without a share: they leave before copying the tree
+  if (uint64_t(blockIdx.x) * (kBlock / 64) * share >= total) return;
+  uint32_t* stack32;
+  const uint4* node_words = stage_nodes<STAGED>(sc, lds_dynamic, stack32);
+  typename F::stack_t* stack = reinterpret_cast<typename F::stack_t*>(stack32 - threadIdx.x) + threadIdx.x;
   const uint64_t begin = uint64_t(blockIdx.x * (kBlock / 64) + threadIdx.x / 64) * share;
   uint32_t next = begin < total ? uint32_t(begin) : total;
   const uint32_t end = begin + share < total ? uint32_t(begin + share) : total;
