@@ -1358,6 +1358,8 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
 
   constexpr uint32_t kDone = F::kNone;     // has the leaf bit set, so it also ends the node loop
   const uint32_t lane = threadIdx.x & 63u;
+  static_assert(kShards == 64, "one region's prefix per lane");
+  const uint32_t my_prefix = s_prefix[lane], my_prefix_end = s_prefix[lane + 1];   // list entries before / through region `lane`
   uint32_t n_nodes = 0, n_prims = 0;
   uint32_t w_nodes = 0, w_prims = 0, w_service = 0, n_service = 0;   // COUNT only: wave-level iterations per phase
   uint32_t entry = RT_MISS;                // queue entry whose ray this lane is working on
@@ -1396,8 +1398,13 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
     const unsigned long long idle = __ballot(entry == RT_MISS);
     if (idle && next < end) {
       const uint32_t g = next + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
+      // the idle lanes take consecutive list positions, nearly always inside one region: the region of the first is found
+      // with one wave-wide comparison against the prefix value each lane holds, and only a run that crosses into the next
+      // region searches
+      const uint32_t first_region = uint32_t(__popcll(__ballot(my_prefix <= next))) - 1u;
+      const uint32_t first_region_end = uint32_t(__builtin_amdgcn_readlane(int(my_prefix_end), int(first_region)));
       if (entry == RT_MISS && g < end) {
-        const uint32_t region = find_region(s_prefix, g);
+        const uint32_t region = g < first_region_end ? first_region : find_region(s_prefix, g);
         entry = region * region_entries + (g - s_prefix[region]);   // the mesh class of a level sits at the front of its regions
         if (mesh.entries) entry = mesh.entries[entry];               // level 0: positions of the listed primary rays
         const double2 oz_dx = q.oz_dx()[entry], d_yz = q.d_yz()[entry];

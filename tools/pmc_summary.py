@@ -9,6 +9,11 @@ per-launch means bench.py's roofline terms are formed from.
   valu_busy                    SQ_ACTIVE_INST_VALU (quad-cycles) * 4 / (1024 SIMDs * cycles), cycles = GRBM_GUI_ACTIVE / 8
                                (rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs)
   clock_ghz                    cycles / the dispatch's own duration (End_Timestamp - Start_Timestamp)
+
+Only the launches of the run's last render are used: bench.py ends with a render that brackets every launch with HIP
+events (one batch at a time, no overlap between batches), preceded by one that counts traversal steps with the
+instrumented kernel variants. The launches after the last instrumented one are therefore the same population as the
+live launch times bench.py divides these counters by.
 usage: tools/pmc_summary.py <profile dir> <workload>/<rule> [out.json]"""
 import collections, csv, glob, json, sys
 from pathlib import Path
@@ -19,17 +24,25 @@ KERNELS = ("traverse_kernel", "shade_start_kernel", "shade_extended_kernel", "sh
            "bounce_kernel", "tail_kernel", "emit_kernel", "resolve_kernel")
 vals = collections.defaultdict(lambda: collections.defaultdict(dict))     # kernel -> counter -> {dispatch: value}
 dur = collections.defaultdict(dict)                                        # kernel -> {(pass, dispatch): ns}
+def counting_variant(k, name):
+    """the instantiations that count traversal steps are an instrument, not the product kernel"""
+    if "<" not in name:
+        return False
+    targs = [a.strip() for a in name[name.index("<") + 1:name.rindex(">")].split(",")]
+    return (k == "traverse_kernel" and targs[2] == "true") or (k == "bounce_kernel" and targs[2] == "true")
+
+
 for f in glob.glob("%s/pmc_*/**/*counter_collection.csv" % prof, recursive=True):
     pass_name = f[len(prof):].strip("/").split("/")[0]
+    rows = []
     for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"]
-        k = next((k for k in KERNELS if k in name), None)
-        if not k:
+        k = next((k for k in KERNELS if k in r["Kernel_Name"]), None)
+        if k:
+            rows.append((k, r))
+    last_counting = max([int(r["Dispatch_Id"]) for k, r in rows if counting_variant(k, r["Kernel_Name"])], default=-1)
+    for k, r in rows:
+        if int(r["Dispatch_Id"]) <= last_counting:
             continue
-        if "<" in name:    # the instantiations that count traversal steps are an instrument, not the product kernel
-            targs = [a.strip() for a in name[name.index("<") + 1:name.rindex(">")].split(",")]
-            if (k == "traverse_kernel" and targs[1] == "true") or (k == "bounce_kernel" and targs[2] == "true"):
-                continue
         d = (pass_name, r["Dispatch_Id"])
         vals[k][r["Counter_Name"]][d] = vals[k][r["Counter_Name"]].get(d, 0.0) + float(r["Counter_Value"])
         if pass_name == "pmc_sq":
