@@ -1319,8 +1319,11 @@ constexpr uint32_t kMinWaveShare = RT_MIN_WAVE_SHARE;   // entries; a smaller sh
 #endif
 constexpr uint32_t kMaxRounds = RT_MAX_ROUNDS;
 
+#ifndef RT_TRAVERSE_WAVES
+#define RT_TRAVERSE_WAVES 5
+#endif
 template <int FMT, int RULE, bool COUNT, bool STAGED>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(RT_TRAVERSE_WAVES, RT_TRAVERSE_WAVES)))
 traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries, FixedOrigin origin, uint32_t resident_waves,
                 TraversalCounters* counters) {
   typedef NodeFmt<FMT> F;
@@ -1720,7 +1723,7 @@ void launch_traverse(const DevScene& sc, PathQueue q, MeshList mesh, uint32_t ma
   // the kernel cuts the list into whole rounds of `resident` waves (5 per SIMD at its 96 registers, unless the LDS of
   // the traversal stacks and staged nodes allows fewer workgroups per CU); launch enough workgroups for the most rounds
   const size_t lds = stack_bytes(sc, true);
-  const uint32_t blocks_per_cu = uint32_t(std::min<size_t>(5, lds ? (160 * 1024) / (lds + 1024) : 5));
+  const uint32_t blocks_per_cu = uint32_t(std::min<size_t>(RT_TRAVERSE_WAVES, lds ? (160 * 1024) / (lds + 1024) : RT_TRAVERSE_WAVES));
   const uint32_t resident = 256u * std::max(1u, blocks_per_cu) * (kBlock / 64);
   const size_t waves = std::min<size_t>((size_t(max_in) + kMinWaveShare - 1) / kMinWaveShare, size_t(resident) * kMaxRounds);
   const dim3 grid(uint32_t(std::max<size_t>(1, (std::max<size_t>(waves, resident) + kBlock / 64 - 1) / (kBlock / 64))));
