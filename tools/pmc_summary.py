@@ -11,9 +11,9 @@ per-launch means bench.py's roofline terms are formed from.
   clock_ghz                    cycles / the dispatch's own duration (End_Timestamp - Start_Timestamp)
 
 Only the launches of the run's last render are used: bench.py ends with a render that brackets every launch with HIP
-events (one batch at a time, no overlap between batches), preceded by one that counts traversal steps with the
-instrumented kernel variants. The launches after the last instrumented one are therefore the same population as the
-live launch times bench.py divides these counters by.
+events (one batch at a time, no overlap between batches), and every render of bench.py ends with one tonemap_kernel.
+The launches after the last-but-one tone map are therefore the same population as the live launch times bench.py
+divides these counters by.
 usage: tools/pmc_summary.py <profile dir> <workload>/<rule> [out.json]"""
 import collections, csv, glob, json, sys
 from pathlib import Path
@@ -24,24 +24,19 @@ KERNELS = ("traverse_kernel", "shade_start_kernel", "shade_extended_kernel", "sh
            "bounce_kernel", "tail_kernel", "emit_kernel", "resolve_kernel")
 vals = collections.defaultdict(lambda: collections.defaultdict(dict))     # kernel -> counter -> {dispatch: value}
 dur = collections.defaultdict(dict)                                        # kernel -> {(pass, dispatch): ns}
-def counting_variant(k, name):
-    """the instantiations that count traversal steps are an instrument, not the product kernel"""
-    if "<" not in name:
-        return False
-    targs = [a.strip() for a in name[name.index("<") + 1:name.rindex(">")].split(",")]
-    return (k == "traverse_kernel" and targs[2] == "true") or (k == "bounce_kernel" and targs[2] == "true")
-
-
 for f in glob.glob("%s/pmc_*/**/*counter_collection.csv" % prof, recursive=True):
     pass_name = f[len(prof):].strip("/").split("/")[0]
-    rows = []
+    rows, tonemaps = [], set()
     for r in csv.DictReader(open(f)):
+        if "tonemap_kernel" in r["Kernel_Name"]:
+            tonemaps.add(int(r["Dispatch_Id"]))
         k = next((k for k in KERNELS if k in r["Kernel_Name"]), None)
         if k:
             rows.append((k, r))
-    last_counting = max([int(r["Dispatch_Id"]) for k, r in rows if counting_variant(k, r["Kernel_Name"])], default=-1)
+    ends = sorted(tonemaps)
+    last_but_one = ends[-2] if len(ends) > 1 else -1
     for k, r in rows:
-        if int(r["Dispatch_Id"]) <= last_counting:
+        if int(r["Dispatch_Id"]) <= last_but_one:
             continue
         d = (pass_name, r["Dispatch_Id"])
         vals[k][r["Counter_Name"]][d] = vals[k][r["Counter_Name"]].get(d, 0.0) + float(r["Counter_Value"])
