@@ -272,6 +272,9 @@ def main():
     ap.add_argument("--batch-paths", type=int, default=0, help="path slots per batch of launches (0 = library default)")
     ap.add_argument("--gpu-bvh", action="store_true", help="build the meshes' trees on the GPU (Morton order + radix tree) instead of the host SAH build")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise the launcher, the rendezvous and the merge over gloo")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank renders on device 0 and the merge goes over gloo (RCCL refuses two "
+                         "ranks on one device); the line it prints is not a scaling measurement")
     args = ap.parse_args()
 
     n = max(1, args.gpus)
@@ -304,10 +307,16 @@ def main():
     import torch.distributed as dist
     from raytracing_amd import api, parallel, _lib as L
 
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    stats_device = torch.device("cpu") if args.share_gpu else device     # gloo gathers host tensors
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     hit_rule = L.HIT_FIRST_INDEX if args.rule == "first_index" else L.HIT_NEAREST
     ctx = api.Context(local_rank, args.batch_paths)
@@ -361,14 +370,14 @@ def main():
     fence()
     instrumented_ms = (time.perf_counter() - t1) / timed["steps"] * 1e3
 
-    t = torch.tensor([elapsed, float(segments)], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, float(segments)], dtype=torch.float64, device=stats_device)
     per_rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        gathered = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
-        dist.all_gather(gathered, torch.tensor([elapsed / args.steps * 1e3], dtype=torch.float64, device=device))
+        gathered = [torch.zeros(1, dtype=torch.float64, device=stats_device) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([elapsed / args.steps * 1e3], dtype=torch.float64, device=stats_device))
         per_rank_ms = [float(g[0]) for g in gathered]
         elapsed = float(tmax[0])
     total_segments = float(t[1])
@@ -393,6 +402,7 @@ def main():
                        "bvh_build_s": info.get("bvh_build_ms", 0.0) / 1e3,
                        "bvh_builder": "device_lbvh" if args.gpu_bvh else "host_sah"},
             "world_size": dist.get_world_size() if world > 1 else 1,
+            "backend": dist.get_backend() if world > 1 else None,
             "per_rank_ms_per_step": per_rank_ms,
             "ms_per_step_instrumented": instrumented_ms,
             "roofline": roofline(args, w, info, counted, timed, world),

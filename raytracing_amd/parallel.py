@@ -37,7 +37,14 @@ def rank_share(kind, spp, rank, world):
 def merge_sums(xyz_sum, dst=0, group=None):
     """Sums every rank's per-pixel XYZ buffer onto rank `dst` (one reduce of W*H*3 floats)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.reduce(xyz_sum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if xyz_sum.is_cuda and dist.get_backend(group) == "gloo":
+            # gloo has no reduce for device tensors (a rehearsal with several ranks on one GPU): through the host
+            host = xyz_sum.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
+            if dist.get_rank(group) == dst:
+                xyz_sum.copy_(host)
+        else:
+            dist.reduce(xyz_sum, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return xyz_sum
 
 
