@@ -1187,6 +1187,10 @@ generate_camera_kernel(DevScene sc, BatchDesc b, PathQueue q, uint32_t region_en
 // in the meshes (smaller reported t wins, the earlier object on a tie -- the order the reference's sequential
 // strict-'<' scan produces), hit point and normal for the winner only, shading, and the append of the
 // continuing paths to `out`. A new ray that meets a mesh's box is listed for the next traverse_kernel.
+#ifndef RT_PREFETCH
+#define RT_PREFETCH 1
+#endif
+
 struct ShadeArgs {
   DevScene sc; BatchDesc b; PathQueue in; LevelCounts in_counts; uint32_t region_entries; PathQueue out;
   LevelCounts out_counts; TraceOutputs o;
@@ -1207,6 +1211,21 @@ __device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
 
   const ChunkMap chunk_map = START ? ChunkMap{0, 0, 0, 0} : load_chunk_map(s_chunk_prefix, s_region_fill);
 
+  // Levels >= 1 read their paths one chunk ahead: the record of the chunk after this one is requested just before the
+  // wave reserves its appends -- when little else is live in registers -- so its trip from memory overlaps the atomic's
+  // round trip, the stores and the top of the next iteration instead of standing at the head of it.
+  constexpr bool kAhead = !START && RT_PREFETCH;
+  PathState ps_ahead;
+  ps_ahead.o = mk(0, 0, 0); ps_ahead.d = mk(1, 0, 0); ps_ahead.pixel = ps_ahead.sample = ps_ahead.slot = ps_ahead.remaining = 0;
+  ps_ahead.chain.a = make_uint4(0, 0, 0, 0); ps_ahead.chain.b = make_uint4(0, 0, 0, 0);
+  uint32_t idx_ahead = 0, obj_ahead = RT_MISS;
+  bool active_ahead = false;
+  if (kAhead && blockIdx.x < n_chunks) {
+    const PathQueue& in0 = *(const PathQueue*)&ap->in;
+    active_ahead = queue_position2(chunk_map, ap->region_entries, blockIdx.x, idx_ahead);
+    if (active_ahead) { load_path(in0, idx_ahead, ap->b.max_depth > 16, ps_ahead); obj_ahead = in0.hit_obj()[idx_ahead]; }
+  }
+
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const DevScene& sc = *(const DevScene*)&ap->sc;
     const BatchDesc& b = *(const BatchDesc*)&ap->b;
@@ -1220,13 +1239,17 @@ __device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
     uint32_t idx;
     bool active;
     if (START) { idx = chunk * kBlock + threadIdx.x; active = idx < n_start; }
+    else if (kAhead) { idx = idx_ahead; active = active_ahead; }
     else active = queue_position2(chunk_map, region_entries, chunk, idx);
     PathState ps;
     ps.o = mk(0, 0, 0); ps.d = mk(1, 0, 0); ps.pixel = ps.sample = ps.slot = ps.remaining = 0;
     ps.chain.a = make_uint4(0, 0, 0, 0); ps.chain.b = make_uint4(0, 0, 0, 0);
     Shaded sh;
     sh.alive = false; sh.emits = false; sh.emit_info = 0; sh.no = ps.o; sh.nd = ps.d;
-    if (active) {
+    const uint32_t ahead_obj = obj_ahead;
+    if (kAhead) {
+      if (active) ps = ps_ahead;
+    } else if (active) {
       if (START) active = start_path(b, idx, ps);
       else load_path(in, idx, deep, ps);
     }
@@ -1238,7 +1261,7 @@ __device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
       hit.obj = pre.obj; hit.prim = 0; hit.t = pre.t;
       double t_raw = pre.t_raw;
       uint32_t tri_slot = 0;
-      const uint32_t mesh_obj = sc.n_meshes ? in.hit_obj()[idx] : RT_MISS;
+      const uint32_t mesh_obj = kAhead ? ahead_obj : (sc.n_meshes ? in.hit_obj()[idx] : RT_MISS);
       if (mesh_obj != RT_MISS) {
         const double2 mesh_t = in.hit_t_raw()[idx];
         if (pre.obj == RT_MISS || mesh_t.x < pre.t || (mesh_t.x == pre.t && mesh_obj < pre.obj)) {
@@ -1255,6 +1278,14 @@ __device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
     // a level keeps its paths in two classes per region: those whose ray meets a mesh's box fill it from the front,
     // the others from the back (see number_chunks2)
     const bool meets_mesh = sh.alive && meets_any_mesh(sc, sh.no, sh.nd);
+    if (kAhead) {
+      const uint32_t next_chunk = chunk + gridDim.x;
+      active_ahead = false;
+      if (next_chunk < n_chunks) {
+        active_ahead = queue_position2(chunk_map, region_entries, next_chunk, idx_ahead);
+        if (active_ahead) { load_path(in, idx_ahead, deep, ps_ahead); obj_ahead = in.hit_obj()[idx_ahead]; }
+      }
+    }
     const Appends ap3 = reserve_appends(o.emit_counts, out_counts.mesh, out_counts.other, region_entries, chunk, sh.emits, meets_mesh,
                                         sh.alive && !meets_mesh);
     emit_or_append(sc, o, chunk, deep, ap3, sh.emits, sh.emit_info, ps.slot, ps.chain);
