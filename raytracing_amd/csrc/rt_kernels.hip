@@ -94,6 +94,22 @@ __device__ __forceinline__ V3 xf_vec_t(const double* m, V3 v) {
             (m[2] * v.x + m[6] * v.y) + m[10] * v.z);
 }
 
+// A record of one of the scene's small tables (objects, spheres, lone triangles) at an index every lane of the wave
+// agrees on, fetched through the constant address space: the compiler then issues scalar loads (one fetch per wave
+// through the scalar cache, results in scalar registers) where it would otherwise issue a vector load in which all
+// 64 lanes ask for the same address -- it cannot prove by itself that nothing in the kernel writes these tables --
+// and the fetch no longer queues behind the wave's outstanding vector-memory operations.
+template <class T>
+__device__ __forceinline__ T load_uniform(const T* p) {
+  static_assert(sizeof(T) % 4 == 0 && __is_trivially_copyable(T), "copied word by word");
+  typedef const __attribute__((address_space(4))) uint32_t* ConstWords;
+  const ConstWords src = (ConstWords)(const void*)p;
+  union Words { T v; uint32_t w[sizeof(T) / 4]; __device__ Words() {} } u;
+#pragma unroll
+  for (unsigned k = 0; k < sizeof(T) / 4; ++k) u.w[k] = src[k];   // the words nobody reads are never fetched
+  return u.v;
+}
+
 // ------------------------------------------------------------------------------- Philox4x32-10
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
@@ -451,15 +467,16 @@ __device__ __forceinline__ bool closest_hit(const DevScene& sc, const uint4* __r
   const V3 dn = normalize(d);  // what `identity.inverse() * ray` leaves of the direction (src/geometry/ray.rs:45)
   const RayDir dir = make_ray_dir(dn);
   for (uint32_t i = 0; i < sc.n_objects; ++i) {
-    const DevObject ob = sc.objects[i];
+    const DevObject ob = load_uniform(sc.objects + i);
     double t, t_raw = 0.0;
     uint32_t prim = 0, slot = 0;
     bool ok;
     if (ob.kind != RT_OBJ_MODEL && !meets_box(ob, o, dir)) continue;
     if (ob.kind == RT_OBJ_SPHERE) {
-      ok = sphere_t(sc.spheres[ob.first], o, d, dn, t);
+      const DevSphere sp = load_uniform(sc.spheres + ob.first);
+      ok = sphere_t(sp, o, d, dn, t);
     } else if (ob.kind == RT_OBJ_TRIANGLE) {
-      const DevTopTri& tr = sc.top_tris[ob.first];
+      const DevTopTri tr = load_uniform(sc.top_tris + ob.first);
       ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, tr.frame.len, t_raw, t);
     } else if (!MESH) {
       continue;
@@ -493,14 +510,15 @@ __device__ __forceinline__ void simple_objects(const DevScene& sc, V3 o, V3 d, V
   best.t = 0.0; best.t_raw = 0.0; best.obj = RT_MISS;
   const RayDir dir = make_ray_dir(dn);
   for (uint32_t i = 0; i < sc.n_objects; ++i) {
-    const DevObject ob = sc.objects[i];
+    const DevObject ob = load_uniform(sc.objects + i);
     double t, t_raw = 0.0;
     bool ok;
     if (ob.kind == RT_OBJ_MODEL || !meets_box(ob, o, dir)) continue;
     if (ob.kind == RT_OBJ_SPHERE) {
-      ok = sphere_t(sc.spheres[ob.first], o, d, dn, t);
+      const DevSphere sp = load_uniform(sc.spheres + ob.first);
+      ok = sphere_t(sp, o, d, dn, t);
     } else {
-      const DevTopTri& tr = sc.top_tris[ob.first];
+      const DevTopTri tr = load_uniform(sc.top_tris + ob.first);
       ok = triangle_hit(ld3(tr.v), ld3(tr.v + 3), ld3(tr.v + 6), o, dn, tr.frame.len, t_raw, t);
     }
     if (ok && (best.obj == RT_MISS || t < best.t)) { best.t = t; best.t_raw = t_raw; best.obj = i; }
@@ -512,7 +530,10 @@ __device__ __forceinline__ void simple_objects(const DevScene& sc, V3 o, V3 d, V
 __device__ __forceinline__ bool meets_any_mesh(const DevScene& sc, V3 o, V3 d) {
   const RayDir dir = make_ray_dir(d);
   bool meets = false;
-  for (uint32_t k = 0; k < sc.n_meshes; ++k) meets = meets || meets_box(sc.objects[sc.mesh_objects[k]], o, dir);
+  for (uint32_t k = 0; k < sc.n_meshes; ++k) {
+    const DevObject ob = load_uniform(sc.objects + load_uniform(sc.mesh_objects + k));
+    meets = meets || meets_box(ob, o, dir);
+  }
   return meets;
 }
 
