@@ -1163,7 +1163,7 @@ __device__ __forceinline__ bool pixel_may_see_mesh(const DevScene& sc, const Dev
   if (!(sin_a < 0.1)) return true;                            // enormous pixels: no culling
   const double cos_a = 1.0 - sin_a * sin_a;                   // <= cos of it
   for (uint32_t k = 0; k < sc.n_meshes; ++k) {
-    const DevObject& ob = sc.objects[sc.mesh_objects[k]];
+    const DevObject ob = load_uniform(sc.objects + load_uniform(sc.mesh_objects + k));
     const V3 v = ld3(ob.center) - f;
     const double dist = sqrt(dot(v, v));
     const double sin_b = ob.radius * 1.000001 / dist;         // sine of the sphere's angular radius
@@ -1472,17 +1472,21 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
       next = end - next < taken ? end : next + taken;
     }
     if (cur == kDone && lf == kNoLeaf && entry != RT_MISS) {   // enter mesh m
-      const DevObject& ob = sc.objects[sc.mesh_objects[m]];
-      const BoxRay br = make_box_ray(o, dn, ob);
-      qr = make_quant_ray(br, ob);
-      root = ob.root; first_tri = ob.first;
-      mh.t = INFINITY; mh.t_raw = 0.0; mh.index = RT_MISS; mh.slot = 0;
-      cur = 0; sp = 0;
-      if (!model_gate_certain(ob, br)) {
-        // the reference's own box test of the model, on the ray as it was built (the direction before re-normalisation)
-        const double2 oz_dx = q.oz_dx()[entry], d_yz = q.d_yz()[entry];
-        if (!model_gate_exact(ob.gate_lo, ob.gate_hi, o, mk(oz_dx.y, d_yz.x, d_yz.y))) cur = kDone;
-      }
+      auto enter = [&](const DevObject& ob) {
+        const BoxRay br = make_box_ray(o, dn, ob);
+        qr = make_quant_ray(br, ob);
+        root = ob.root; first_tri = ob.first;
+        mh.t = INFINITY; mh.t_raw = 0.0; mh.index = RT_MISS; mh.slot = 0;
+        cur = 0; sp = 0;
+        if (!model_gate_certain(ob, br)) {
+          // the reference's own box test of the model, on the ray as it was built (the direction before re-normalisation)
+          const double2 oz_dx = q.oz_dx()[entry], d_yz = q.d_yz()[entry];
+          if (!model_gate_exact(ob.gate_lo, ob.gate_hi, o, mk(oz_dx.y, d_yz.x, d_yz.y))) cur = kDone;
+        }
+      };
+      // a scene with one mesh (the usual case): its record is the same for every lane and comes through scalar loads
+      if (sc.n_meshes == 1) { const DevObject ob = load_uniform(sc.objects + load_uniform(sc.mesh_objects)); enter(ob); }
+      else enter(sc.objects[sc.mesh_objects[m]]);
     }
     if (__ballot(entry != RT_MISS) == 0) break;
     const bool refillable = next < end;
