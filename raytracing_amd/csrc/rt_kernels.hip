@@ -434,23 +434,44 @@ struct Hit {
   uint32_t obj, prim;
   double t;
   V3 p, n;
+  DevMaterial mat;
 };
 
-// Hit point and normal of the winning object only.
-__device__ __forceinline__ void hit_geometry(const DevScene& sc, const DevObject& ob, V3 o, V3 d, V3 dn, double t, double t_raw,
-                                             uint32_t tri_slot, V3& p, V3& n) {
+__device__ __forceinline__ void sphere_surface(const DevSphere& s, V3 o, V3 d, V3 dn, double t, V3& p, V3& n) {
+  V3 lo, ld;
+  sphere_local_ray(s, o, d, dn, lo, ld);
+  const V3 pl = lo + ld * t;
+  p = xf_pt(s.l2w, pl);                        // src/shapes/sphere.rs:98
+  n = normalize(xf_vec_t(s.w2l, pl));          // src/shapes/sphere.rs:37-43
+}
+
+// Hit point, normal and material of the winning object only. When every lane that is here hit the same object (primary
+// rays on one sphere, bounce rays on the ground) its records come through scalar loads; otherwise each lane gathers its own.
+__device__ __forceinline__ void hit_surface(const DevScene& sc, uint32_t obj, V3 o, V3 d, V3 dn, double t, double t_raw,
+                                            uint32_t tri_slot, V3& p, V3& n, DevMaterial& mat) {
+  const uint32_t obj0 = uint32_t(__builtin_amdgcn_readfirstlane(int(obj)));
+  if (__ballot(obj != obj0) == 0) {
+    const DevObject ob = load_uniform(sc.objects + obj0);
+    if (ob.kind == RT_OBJ_SPHERE) {
+      const DevSphere s = load_uniform(sc.spheres + ob.first);
+      sphere_surface(s, o, d, dn, t, p, n);
+    } else {
+      p = o + dn * t_raw;                                        // src/shapes/triangle.rs:78-81
+      if (ob.kind == RT_OBJ_TRIANGLE) { const DevTopTri tr = load_uniform(sc.top_tris + ob.first); n = ld3(tr.frame.n); }
+      else n = ld3(sc.mesh_frames[ob.first + tri_slot].n);       // src/shapes/triangle.rs:30, then :91
+    }
+    mat = load_uniform(sc.materials + ob.material);
+    return;
+  }
+  const DevObject& ob = sc.objects[obj];
   if (ob.kind == RT_OBJ_SPHERE) {
-    const DevSphere& s = sc.spheres[ob.first];
-    V3 lo, ld;
-    sphere_local_ray(s, o, d, dn, lo, ld);
-    const V3 pl = lo + ld * t;
-    p = xf_pt(s.l2w, pl);                        // src/shapes/sphere.rs:98
-    n = normalize(xf_vec_t(s.w2l, pl));          // src/shapes/sphere.rs:37-43
+    sphere_surface(sc.spheres[ob.first], o, d, dn, t, p, n);
   } else {
     const DevTriFrame& f = ob.kind == RT_OBJ_TRIANGLE ? sc.top_tris[ob.first].frame : sc.mesh_frames[ob.first + tri_slot];
-    p = o + dn * t_raw;                                          // src/shapes/triangle.rs:78-81
-    n = ld3(f.n);                                                // src/shapes/triangle.rs:30, then :91
+    p = o + dn * t_raw;
+    n = ld3(f.n);
   }
+  mat = sc.materials[ob.material];
 }
 
 // Scene::intersect_ray (src/scene.rs:135-150): closest over the object list in scene order,
@@ -499,7 +520,7 @@ __device__ __forceinline__ bool closest_hit(const DevScene& sc, const uint4* __r
   }
   if (!found) return false;
   hit.obj = best_obj; hit.prim = best_prim; hit.t = best_t;
-  hit_geometry(sc, sc.objects[best_obj], o, d, dn, best_t, best_raw, best_slot, hit.p, hit.n);
+  hit_surface(sc, best_obj, o, d, dn, best_t, best_raw, best_slot, hit.p, hit.n, hit.mat);
   return true;
 }
 
@@ -824,7 +845,7 @@ __device__ __forceinline__ Shaded shade_hit(const DevScene& sc, const BatchDesc&
   bool contributes = false;
   float* spectrum_out = o.spectra ? o.spectra + size_t(s.slot) * RT_NBINS : nullptr;
   if (found) {
-    const DevMaterial m = sc.materials[sc.objects[hit.obj].material];
+    const DevMaterial m = hit.mat;
     if (b.integrator == RT_INT_ALBEDO) {
       // first present of ambient / emitted / diffused / specular (src/integrators/albedo.rs:54-68)
       uint32_t row = RT_NO_SPECTRUM;
@@ -1292,7 +1313,7 @@ __device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
         }
       }
       const bool found = hit.obj != RT_MISS;
-      if (found) hit_geometry(sc, sc.objects[hit.obj], ps.o, ps.d, dn, hit.t, t_raw, tri_slot, hit.p, hit.n);
+      if (found) hit_surface(sc, hit.obj, ps.o, ps.d, dn, hit.t, t_raw, tri_slot, hit.p, hit.n, hit.mat);
       const bool first_hit = b.integrator != RT_INT_RANDOM_WALK || ps.remaining == b.max_depth;
       sh = shade_hit<EXT>(sc, b, o, found, hit, first_hit, ps);
     }
