@@ -106,7 +106,9 @@ __device__ __forceinline__ T load_uniform(const T* p) {
   const ConstWords src = (ConstWords)(const void*)p;
   union Words { T v; uint32_t w[sizeof(T) / 4]; __device__ Words() {} } u;
 #pragma unroll
-  for (unsigned k = 0; k < sizeof(T) / 4; ++k) u.w[k] = src[k];   // the words nobody reads are never fetched
+  // the words nobody reads are never fetched; the first-lane read pins a word to a scalar register, so that the fetch
+  // stays a scalar load also where every use of the word is a vector instruction
+  for (unsigned k = 0; k < sizeof(T) / 4; ++k) u.w[k] = uint32_t(__builtin_amdgcn_readfirstlane(int(src[k])));
   return u.v;
 }
 
