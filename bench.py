@@ -164,7 +164,7 @@ def roofline(args, w, scene_info, counted, timed, world):
 
       hbm        counter bytes per launch (FETCH_SIZE doubled + WRITE_SIZE, committed PMC pass) / live launch time / 8 TB/s
       valu       lane-instructions per launch (SQ_THREAD_CYCLES_VALU, committed PMC pass) / live launch time, against one
-                 wave64 vector instruction per SIMD per 4 cycles at the clock the profiled launch ran at -- what
+                 wave64 vector instruction per SIMD per 4 cycles at the chip's maximum clock -- what
                  SQ_ACTIVE_INST_VALU charges every instruction and what a binary64 instruction really takes; a binary32
                  instruction can issue in 2, so for binary32-heavy code this ceiling is low by up to 2x and the fraction
                  high by as much (frac_if_all_binary32 is the other end)
@@ -204,12 +204,15 @@ def roofline(args, w, scene_info, counted, timed, world):
             gbs = traffic / secs / 1e9
             terms["hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
         if pmc.get("lane_instructions_per_launch"):
-            clock = pmc.get("clock_ghz") or MAX_CLOCK_GHZ
+            # the peak is taken at the chip's maximum clock: the live launches are not the profiled ones, and a peak at the
+            # (lower) clock of the profiled run would flatter a launch that ran faster live
+            clock = MAX_CLOCK_GHZ
             peak = N_SIMD * WAVE * clock / 4.0 / 1e3                       # T lane-instructions / s
             ach = pmc["lane_instructions_per_launch"] / secs / 1e12
             terms["valu"] = {"achieved": ach, "peak": peak, "unit": "Tlane-instr/s", "frac": ach / peak,
                              "frac_if_all_binary32": ach / (2.0 * peak), "valu_busy": pmc.get("valu_busy"),
-                             "lane_utilisation": pmc.get("lane_utilisation"), "clock_ghz": clock,
+                             "lane_utilisation": pmc.get("lane_utilisation"), "peak_clock_ghz": clock,
+                             "profiled_clock_ghz": pmc.get("clock_ghz"),
                              "profiled_launch_ms": pmc.get("launch_ms")}
     candidates = {k: v for k, v in terms.items() if k != "algorithmic" or v["counts_as_hbm_roof"]}
     if "valu" not in terms:   # no counter pass committed for this workload: the flop model stands in for the VALU term

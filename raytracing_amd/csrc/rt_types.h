@@ -111,14 +111,16 @@ struct DevMeshTri {
 };
 static_assert(sizeof(DevMeshTri) == 80, "DevMeshTri must be 80 bytes");
 
-struct DevMaterial {
+// 32 bytes on a 16-byte boundary: a record read at a wave-uniform index then comes with two aligned scalar loads
+struct alignas(16) DevMaterial {
   uint32_t type;
   uint32_t present;
   uint8_t ambient, emitted, diffused, specular;  // rows of the spectrum table, RT_NO_SPECTRUM if absent
   float ns;            // exponent of the glossy lobe
   float ni;            // refractive index of a dielectric
-  uint32_t pad;
+  uint32_t pad[3];
 };
+static_assert(sizeof(DevMaterial) == 32, "DevMaterial must be 32 bytes");
 
 struct DevScene {
   const DevObject* objects;
