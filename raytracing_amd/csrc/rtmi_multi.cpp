@@ -54,9 +54,10 @@ struct Rccl {
   static constexpr int kFloat32 = 7, kSum = 0;   // ncclFloat32, ncclSum (rccl.h)
 };
 
-Rccl* load_rccl() {
+Rccl* load_rccl(std::string* why_not = nullptr) {
   static Rccl r;
   static bool tried = false;
+  if (why_not) *why_not = r.error;
   if (tried) return r.lib ? &r : nullptr;
   tried = true;
   std::vector<std::pair<std::string, int>> candidates;
@@ -88,6 +89,8 @@ Rccl* load_rccl() {
     r.error = c.first + " lacks an RCCL entry point";
     dlclose(h);
   }
+  if (r.error.empty()) r.error = "no librccl.so next to the HIP runtime or on the loader path";
+  if (why_not) *why_not = r.error;
   return nullptr;
 }
 
@@ -168,9 +171,10 @@ extern "C" int rtmi_multi_create(const int* device_ids, int n, uint64_t max_batc
   // Ranks that share a GPU (more shares than devices) cannot form an RCCL communicator: their sums are merged by copies
   // to the first device and adds.
   if (all_distinct && (n > 1 || getenv("RTMI_RCCL_SINGLE"))) {
-    m->rccl = load_rccl();
+    std::string why_not;
+    m->rccl = load_rccl(&why_not);
     if (!m->rccl) return fail(RTMI_RCCL_ERROR, "RCCL could not be loaded (%s); set RTMI_RCCL_LIB to the librccl.so of this process's HIP runtime",
-                              load_rccl() ? "" : "no librccl.so found next to the HIP runtime or on the loader path");
+                              why_not.c_str());
     std::vector<Rccl::comm_t> comms(size_t(n), nullptr);
     std::vector<int> devs;
     for (const Rank& r : m->ranks) devs.push_back(r.device);
@@ -268,14 +272,17 @@ int render_samples(rtmi_multi* m, const rtmi_camera* cam, const rtmi_render_para
   Rank& root = m->ranks[0];
   if (m->rccl) {
     int rc = m->rccl->GroupStart();
-    for (size_t i = 0; i < n && rc == 0; ++i) {
+    hipError_t hip_rc = hipSuccess;
+    for (size_t i = 0; i < n && rc == 0 && hip_rc == hipSuccess; ++i) {
       Rank& r = m->ranks[i];
-      HIP_TRY(hipSetDevice(r.device));
+      hip_rc = hipSetDevice(r.device);
       // the receive buffer only matters on the root; the ranks' own sums stay as they are for the next pass
-      rc = m->rccl->Reduce(r.sums, i == 0 ? m->total : r.sums, n_pix * 3, Rccl::kFloat32, Rccl::kSum, 0, r.comm, r.stream);
+      if (hip_rc == hipSuccess)
+        rc = m->rccl->Reduce(r.sums, i == 0 ? m->total : r.sums, n_pix * 3, Rccl::kFloat32, Rccl::kSum, 0, r.comm, r.stream);
     }
-    const int rc_end = m->rccl->GroupEnd();
+    const int rc_end = m->rccl->GroupEnd();   // the group is closed on every path, also after a failed call inside it
     if (rc == 0) rc = rc_end;
+    if (hip_rc != hipSuccess) return fail(RTMI_HIP_ERROR, "hipSetDevice before ncclReduce: %s", hipGetErrorString(hip_rc));
     if (rc != 0) return fail(RTMI_RCCL_ERROR, "ncclReduce of %zu floats over %zu ranks: %s", n_pix * 3, n, m->rccl->GetErrorString(rc));
     for (Rank& r : m->ranks) { HIP_TRY(hipSetDevice(r.device)); HIP_TRY(hipStreamSynchronize(r.stream)); }
   } else {
