@@ -29,10 +29,10 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, ~8 TB/s
 N_SIMD, WAVE = 256 * 4, 64   # 256 CUs x 4 SIMDs, 64 lanes per wave
 MAX_CLOCK_GHZ = 2.4
 L2_BYTES, INFINITY_CACHE_BYTES = 32 << 20, 256 << 20
-NODE_BYTES, TRI_BYTES = 64, 80      # a BVH node; a mesh triangle (f64 vertices + file-order index)
+TRI_BYTES = 80                      # a mesh triangle (f64 vertices + file-order index); a BVH node is 32 or 48 bytes (scene info)
 # Algorithmic bytes per unit of the two kernels a roofline is quoted for:
 #   traverse_kernel, per listed ray: list entry (4) + ray origin and direction (48) + the hit record it folds its result
-#     into (12 read, 28 written) + the BVH nodes and triangles that ray visits
+#     into (12 read, 28 written) + the BVH nodes (at the scene's real node size) and triangles that ray visits
 #   bounce_kernel (scenes without meshes), per segment: one path-state record read and one written (6 f64 + 4 u32 + 16
 #     chain bytes each)
 TRAVERSE_RAY_BYTES = 4 + 48 + 12 + 28
@@ -159,18 +159,32 @@ def committed_counters(workload, rule, kernel):
         return None
 
 
-def roofline(args, w, scene_info, counted, timed, world):
-    """Every term a launch of the dominant kernel could be bound by, and the one that binds.
+def running_source_hash():
+    try:
+        sys.path.insert(0, str(ROOT / "tools"))
+        from source_hash import source_hash
+        return source_hash()
+    except Exception:
+        return None
 
-      hbm        counter bytes per launch (FETCH_SIZE doubled + WRITE_SIZE, committed PMC pass) / live launch time / 8 TB/s
-      valu       lane-instructions per launch (SQ_THREAD_CYCLES_VALU, committed PMC pass) / live launch time, against one
-                 wave64 vector instruction per SIMD per 4 cycles at the chip's maximum clock -- what
-                 SQ_ACTIVE_INST_VALU charges every instruction and what a binary64 instruction really takes; a binary32
-                 instruction can issue in 2, so for binary32-heavy code this ceiling is low by up to 2x and the fraction
-                 high by as much (frac_if_all_binary32 is the other end)
-      algorithmic  every node, triangle and record fetch charged to memory (the per-unit byte model): what the traffic
-                 would be with no cache at all; it exceeds the HBM term by the cache hit ratio and is a fraction of a
-                 roof only when the tree does not fit the 256 MiB Infinity Cache
+
+def roofline(args, w, scene_info, counted, timed, world):
+    """Roofline of the dominant kernel (traverse_kernel with meshes, bounce_kernel without), per launch.
+
+    The headline figures (`achieved`, `peak`, `frac`, `bound`) are ALGORITHMIC: the per-unit model of the work a launch
+    has to do, times the units the launch processed, over the launch's live duration (HIP events on the stream the
+    kernel runs on). Two model terms exist and the one that can bind is quoted:
+      algorithmic_flops  FP64-equivalent flops per unit (40 per node visit, 55 per triangle test, plus shading and the
+                         analytic objects for the fused kernel) against the 78.6 TFLOP/s vector-FP64 peak -> bound "valu"
+      algorithmic_bytes  bytes per unit with every node, triangle and record fetch charged to memory, against 8 TB/s ->
+                         bound "hbm". It is a roof only when the tree exceeds the 256 MiB Infinity Cache (otherwise
+                         node fetches are served from LDS or cache and the term can exceed 1); it is always printed.
+    Beside them, from the committed rocprofv3 counter passes of the same workload (profiles/pmc_summary.json), divided
+    by the same live launch time -- how busy the hardware was, whatever it was busy with:
+      hbm_counters         2 * FETCH_SIZE + WRITE_SIZE per launch against 8 TB/s (`traffic` is this byte count)
+      valu_issue_counters  executed lane-instructions per launch (SQ_THREAD_CYCLES_VALU) against one wave64 vector
+                           instruction per SIMD per 4 cycles at the maximum clock = valu_busy x lane_utilisation
+    `counters_from` names the file, or says "stale" when the profiled sources are not the ones being timed.
     """
     two_kernel = timed["traverse_launches"] > 0
     if two_kernel:
@@ -183,9 +197,10 @@ def roofline(args, w, scene_info, counted, timed, world):
         units = timed["segments"]
         per_unit = max(1, counted["segments"])
         base_bytes, k_ms, k_launches = 2 * STATE_BYTES, timed["ms_kernels"], timed["launches"]
+    node_bytes = scene_info["node_bytes"] / scene_info["n_nodes"] if scene_info.get("n_nodes") else 0.0
     nodes_per_unit = counted["nodes_visited"] / per_unit
     tris_per_unit = counted["prims_tested"] / per_unit
-    bytes_per_unit = base_bytes + nodes_per_unit * NODE_BYTES + tris_per_unit * TRI_BYTES
+    bytes_per_unit = base_bytes + nodes_per_unit * node_bytes + tris_per_unit * TRI_BYTES
     avg_ms = k_ms / max(1, k_launches)
     secs = avg_ms * 1e-3
     units_per_launch = units / max(1, k_launches)
@@ -193,41 +208,49 @@ def roofline(args, w, scene_info, counted, timed, world):
     flops_per_unit = nodes_per_unit * NODE_FLOPS + tris_per_unit * TRI_FLOPS + (0 if two_kernel else SHADE_FLOPS)
     model_tflops = units_per_launch * flops_per_unit / secs / 1e12 if secs > 0 else 0.0
     tree_bytes = scene_info["node_bytes"] + scene_info["triangle_bytes"]
-    terms = {"algorithmic": {"achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algorithmic_gbs / HBM_PEAK_GBS,
-                             "bytes_per_unit": bytes_per_unit, "counts_as_hbm_roof": tree_bytes > INFINITY_CACHE_BYTES,
-                             "tree_bytes": tree_bytes}}
+    bytes_bind = tree_bytes > INFINITY_CACHE_BYTES
+    terms = {"algorithmic_flops": {"achieved": model_tflops, "peak": VALU_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": model_tflops / VALU_F64_PEAK_TFLOPS, "flops_per_unit": flops_per_unit},
+             "algorithmic_bytes": {"achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": algorithmic_gbs / HBM_PEAK_GBS,
+                                   "bytes_per_unit": bytes_per_unit, "node_bytes": node_bytes, "counts_as_hbm_roof": bytes_bind,
+                                   "tree_bytes": tree_bytes}}
     pmc = committed_counters(args.workload, args.rule, kernel)
     traffic = None
+    counters_from = None
     if pmc and secs > 0:
+        running = running_source_hash()
+        profiled = pmc.get("source_hash")
+        counters_from = "profiles/pmc_summary.json"
+        if profiled is None or running is None or profiled != running:
+            counters_from = "stale: profiles/pmc_summary.json was taken from sources %s, this run times %s" % (profiled, running)
         traffic = pmc.get("hbm_bytes_per_launch")
         if traffic is not None:
             gbs = traffic / secs / 1e9
-            terms["hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+            terms["hbm_counters"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                     "l2_hit_rate": pmc.get("l2_hit_rate")}
         if pmc.get("lane_instructions_per_launch"):
             # the peak is taken at the chip's maximum clock: the live launches are not the profiled ones, and a peak at the
             # (lower) clock of the profiled run would flatter a launch that ran faster live
             clock = MAX_CLOCK_GHZ
             peak = N_SIMD * WAVE * clock / 4.0 / 1e3                       # T lane-instructions / s
             ach = pmc["lane_instructions_per_launch"] / secs / 1e12
-            terms["valu"] = {"achieved": ach, "peak": peak, "unit": "Tlane-instr/s", "frac": ach / peak,
-                             "frac_if_all_binary32": ach / (2.0 * peak), "valu_busy": pmc.get("valu_busy"),
-                             "lane_utilisation": pmc.get("lane_utilisation"), "peak_clock_ghz": clock,
-                             "profiled_clock_ghz": pmc.get("clock_ghz"),
-                             "profiled_launch_ms": pmc.get("launch_ms")}
-    candidates = {k: v for k, v in terms.items() if k != "algorithmic" or v["counts_as_hbm_roof"]}
-    if "valu" not in terms:   # no counter pass committed for this workload: the flop model stands in for the VALU term
-        candidates["valu_model"] = {"achieved": model_tflops, "peak": VALU_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": model_tflops / VALU_F64_PEAK_TFLOPS}
-        terms["valu_model"] = candidates["valu_model"]
-    bound = max(candidates, key=lambda k: candidates[k]["frac"])
-    b = candidates[bound]
-    return {"bound": {"algorithmic": "hbm", "valu_model": "valu"}.get(bound, bound), "achieved": b["achieved"], "peak": b["peak"],
+            terms["valu_issue_counters"] = {"achieved": ach, "peak": peak, "unit": "Tlane-instr/s", "frac": ach / peak,
+                                            "valu_busy": pmc.get("valu_busy"), "lane_utilisation": pmc.get("lane_utilisation"),
+                                            "lane_instructions_per_unit": pmc["lane_instructions_per_launch"] / max(1.0, units_per_launch),
+                                            "peak_clock_ghz": clock, "profiled_clock_ghz": pmc.get("clock_ghz"),
+                                            "profiled_launch_ms": pmc.get("launch_ms")}
+    bound = "algorithmic_bytes" if bytes_bind and terms["algorithmic_bytes"]["frac"] >= terms["algorithmic_flops"]["frac"] else "algorithmic_flops"
+    b = terms[bound]
+    issue = terms.get("valu_issue_counters", {}).get("frac")
+    hbm = terms.get("hbm_counters", {}).get("frac")
+    return {"bound": "hbm" if bound == "algorithmic_bytes" else "valu", "achieved": b["achieved"], "peak": b["peak"],
             "unit": b["unit"], "frac": b["frac"], "traffic": traffic, "binding_term": bound,
+            "counter_issue_frac": issue, "counter_hbm_frac": hbm,
             "kernel": kernel, "launches": k_launches, "avg_launch_ms": avg_ms, "unit_of_work": unit_name,
             "units_per_launch": units_per_launch, "nodes_per_unit": nodes_per_unit, "triangles_per_unit": tris_per_unit,
-            "flops_per_unit": flops_per_unit, "all_kernels_ms_per_step": timed["ms_kernels"] / max(1, timed["steps"]),
-            "all_launches": timed["launches"], "terms": terms,
-            "counters_from": "profiles/pmc_summary.json" if pmc else None}
+            "flops_per_unit": flops_per_unit, "bytes_per_unit": bytes_per_unit,
+            "all_kernels_ms_per_step": timed["ms_kernels"] / max(1, timed["steps"]),
+            "all_launches": timed["launches"], "terms": terms, "counters_from": counters_from}
 
 
 # ------------------------------------------------------------------------------------------- one rank
@@ -243,7 +266,8 @@ def dry_run(args, world, rank):
     n = 96 * 54 * 3
     t0 = time.perf_counter()
     acc = torch.full((n,), float(rank + 1), dtype=torch.float32)
-    share = parallel.rank_share(args.partition, 64 * world, rank, world)
+    spp_job = 64 * world if args.scaling == "weak" and args.partition == "samples" else 64
+    share = parallel.rank_share(args.partition, spp_job, rank, world)
     parallel.merge_sums(acc, 0)
     if world > 1:
         dist.barrier()
@@ -257,6 +281,7 @@ def dry_run(args, world, rank):
         ok = bool((acc == world * (world + 1) / 2).all())
         print(json.dumps({"metric": "Mpath-segments/sec (whole node)", "value": 0.0, "unit": "Mseg/s", "n_gpus": world, "dry_run": True,
                           "world_size": dist.get_world_size() if world > 1 else 1, "merge_ok": ok, "per_rank": per_rank,
+                          "scaling": "weak" if args.partition == "samples" and args.scaling == "weak" else "strong", "spp_job": spp_job,
                           "steps": args.steps, "warmup": args.warmup}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -270,6 +295,13 @@ def main():
     ap.add_argument("--workload", default="suzanne_1080p_64spp", choices=sorted(WORKLOADS))
     ap.add_argument("--rule", default="first_index", choices=["first_index", "nearest"])
     ap.add_argument("--partition", default="samples", choices=["samples", "tiles"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="samples partition only: weak = every rank renders the workload's spp of an N x spp job (the default, what "
+                         "the line's `scaling` says); strong = the workload's spp are split over the ranks (the 256-spp-over-8-GPUs "
+                         "form of the 1 M-triangle configuration). The tile partition is always strong.")
+    ap.add_argument("--devices", type=int, default=0,
+                    help="one process, this many GPUs behind the C ABI (rtmi_multi_render: partition + ncclReduce inside the library) "
+                         "instead of one process per GPU; prints the same line with backend \"rtmi_multi\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every core this process may use)")
     ap.add_argument("--batch-paths", type=int, default=0, help="path slots per batch of launches (0 = library default)")
@@ -327,7 +359,8 @@ def main():
     scene, cam = build_scene(ctx, w, hit_rule, scene_flags=L.SCENE_GPU_BVH if args.gpu_bvh else 0)
     build_s = time.perf_counter() - t_build
     width, height, spp, depth = cam.width, cam.height, w["spp"], w["depth"]
-    spp_job = spp * world if args.partition == "samples" else spp     # weak scaling in samples
+    weak = args.partition == "samples" and args.scaling == "weak"
+    spp_job = spp * world if weak else spp     # weak scaling in samples: every rank its own spp of an N x spp job
     stream = torch.cuda.current_stream().cuda_stream
     acc = torch.zeros(height * width * 3, dtype=torch.float32, device=device)
     rgb8 = torch.zeros(height * width * 3, dtype=torch.uint8, device=device)
@@ -355,7 +388,8 @@ def main():
         step()                                # no instrumentation, no host synchronisation inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
-    seg_step = scene.collect_stats(stream)["segments"]     # exact, from the fill counters of the last step
+    last = scene.collect_stats(stream)                     # exact, from the fill counters of the last step
+    seg_step, mesh_rays_step = last["segments"], last["mesh_rays"]
     segments = seg_step * args.steps
 
     # untimed: exact traversal counts, then HIP events around every launch (on `stream`) for the roofline terms
@@ -373,7 +407,7 @@ def main():
     fence()
     instrumented_ms = (time.perf_counter() - t1) / timed["steps"] * 1e3
 
-    t = torch.tensor([elapsed, float(segments)], dtype=torch.float64, device=stats_device)
+    t = torch.tensor([elapsed, float(segments), float(mesh_rays_step * args.steps)], dtype=torch.float64, device=stats_device)
     per_rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
         tmax = t.clone()
@@ -383,7 +417,7 @@ def main():
         dist.all_gather(gathered, torch.tensor([elapsed / args.steps * 1e3], dtype=torch.float64, device=stats_device))
         per_rank_ms = [float(g[0]) for g in gathered]
         elapsed = float(tmax[0])
-    total_segments = float(t[1])
+    total_segments, total_mesh_rays = float(t[1]), float(t[2])
 
     if rank == 0:
         info = scene.info()
@@ -393,12 +427,15 @@ def main():
             "unit": "Mseg/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            # the segments that had a mesh to search (their ray meets a mesh's box): the traversal kernel's share of `value`
+            "mesh_rays_per_step": total_mesh_rays / args.steps,
+            "mesh_rays_mps": total_mesh_rays / elapsed / 1e6,
             "higher_is_better": True,
-            "scaling": "weak" if args.partition == "samples" else "strong",
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": args.workload, "width": width, "height": height, "spp_per_gpu": spp if args.partition == "samples" else None,
+            "config": {"workload": args.workload, "width": width, "height": height, "spp_per_gpu": spp if weak else (spp / world if args.partition == "samples" else None),
                        "spp_job": spp_job, "max_depth": depth, "integrator": "RandomWalk", "hit_rule": args.rule,
                        "partition": args.partition, "mesh_triangles": info["n_mesh_triangles"],
                        "segments_per_step_per_gpu": seg_step, "scene_build_s": build_s,

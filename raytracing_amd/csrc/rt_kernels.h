@@ -124,7 +124,11 @@ struct TraceOutputs {
 // nodes, prims: lane-level work. The *_slots fields count 64 per wave-level iteration of the traversal kernel's node
 // loop, triangle loop and service block (and service_lanes the lanes actually serviced), so that
 // nodes / node_slots etc. give the lane occupancy of each phase.
-struct TraversalCounters { unsigned long long nodes, prims, node_slots, prim_slots, service_slots, service_lanes; };
+// idle[]: what the lanes that sat a step out were doing -- node steps: [0] finished, waiting to be serviced, [1] no ray
+// (the wave's share is used up), [2] holding a second leaf while the first is still parked, [3] walk finished, parked leaf
+// pending; triangle steps: [4] walking (no leaf yet), [5] finished, [6] no ray; [7] node steps again: reached its first leaf earlier in this
+// group of steps.
+struct TraversalCounters { unsigned long long nodes, prims, node_slots, prim_slots, service_slots, service_lanes, idle[8]; };
 
 // copies the spectral tables into the current device's constant memory
 hipError_t upload_constants(const SpectrumTables& t);

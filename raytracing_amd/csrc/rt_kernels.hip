@@ -1440,6 +1440,7 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
   const uint32_t my_prefix = s_prefix[lane], my_prefix_end = s_prefix[lane + 1];   // list entries before / through region `lane`
   uint32_t n_nodes = 0, n_prims = 0;
   uint32_t w_nodes = 0, w_prims = 0, w_service = 0, n_service = 0;   // COUNT only: wave-level iterations per phase
+  uint32_t n_idle[8] = {0, 0, 0, 0, 0, 0, 0, 0};                      // COUNT only: see TraversalCounters::idle
   uint32_t entry = RT_MISS;                // queue entry whose ray this lane is working on
   V3 o = mk(0, 0, 0), dn = mk(1, 0, 0);
   QuantRay qr = {};
@@ -1534,7 +1535,10 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
       if (uint32_t(__popcll(__ballot(serviceable))) >= kRefillLanes) break;
       if (n_walking >= n_leaf) {
 #pragma unroll
-        for (int rep = 0; rep < RT_NODE_UNROLL; ++rep) if (!(cur & F::kLeaf)) {
+        for (int rep = 0; rep < RT_NODE_UNROLL; ++rep) {
+          if (COUNT && __ballot(!(cur & F::kLeaf)) != 0 && (cur & F::kLeaf))
+            ++n_idle[entry == RT_MISS ? 1 : (cur != kDone ? (lf != kNoLeaf ? 2 : 7) : (lf != kNoLeaf ? 3 : 0))];
+          if (!(cur & F::kLeaf)) {
           if (COUNT) count_slot(w_nodes);
           if (COUNT) ++n_nodes;
           const float tmax = RULE == RT_HIT_NEAREST ? __double2float_ru(mh.t) * 1.000002f : INFINITY;
@@ -1554,8 +1558,11 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
           } else {
             cur = sp ? stack[(--sp) * kBlock] : kDone;
           }
+          }
         }
-      } else if (has_leaf) {
+      } else {
+        if (COUNT && !has_leaf) ++n_idle[entry == RT_MISS ? 6 : (walking ? 4 : 5)];
+        if (has_leaf) {
         if (COUNT) count_slot(w_prims);
         const uint32_t slot = (lf & ~RT_LEAF_FLAG) >> 4;
         const DevMeshTri* tp = sc.mesh_tris + first_tri + slot;
@@ -1582,15 +1589,19 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
           leaf_done = leaf_done || (lf & 15u) == 0u;
         }
         if (leaf_done) lf = kNoLeaf;
+        }
       }
     }
   }
 
   if (COUNT) {
-    unsigned long long v[6] = {n_nodes, n_prims, w_nodes, w_prims, w_service, n_service};
-    unsigned long long* dst[6] = {&counters->nodes, &counters->prims, &counters->node_slots, &counters->prim_slots,
-                                  &counters->service_slots, &counters->service_lanes};
-    for (int k = 0; k < 6; ++k) {
+    unsigned long long v[14] = {n_nodes, n_prims, w_nodes, w_prims, w_service, n_service, n_idle[0], n_idle[1], n_idle[2], n_idle[3],
+                                n_idle[4], n_idle[5], n_idle[6], n_idle[7]};
+    unsigned long long* dst[14] = {&counters->nodes, &counters->prims, &counters->node_slots, &counters->prim_slots,
+                                   &counters->service_slots, &counters->service_lanes, &counters->idle[0], &counters->idle[1],
+                                   &counters->idle[2], &counters->idle[3], &counters->idle[4], &counters->idle[5], &counters->idle[6],
+                                   &counters->idle[7]};
+    for (int k = 0; k < 14; ++k) {
       for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
       if (lane == 0) atomicAdd(dst[k], v[k]);
     }

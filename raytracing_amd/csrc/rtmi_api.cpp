@@ -1082,12 +1082,19 @@ extern "C" int rtmi_render_collect_stats(rtmi_scene* s, void* stream_, rtmi_stat
     stats->nodes_visited += h.trav.nodes; stats->prims_tested += h.trav.prims; stats->mesh_rays += h.mesh_rays;
     trav.nodes += h.trav.nodes; trav.prims += h.trav.prims; trav.node_slots += h.trav.node_slots; trav.prim_slots += h.trav.prim_slots;
     trav.service_slots += h.trav.service_slots; trav.service_lanes += h.trav.service_lanes;
+    for (int k = 0; k < 8; ++k) trav.idle[k] += h.trav.idle[k];
   }
   if (getenv("RTMI_VERBOSE") && trav.node_slots)
     std::fprintf(stderr, "rtmi: traversal lane occupancy: node loop %.1f %% (%llu steps), triangle loop %.1f %% (%llu tests), "
                  "service block %.1f %% (%llu lanes)\n", 100.0 * trav.nodes / trav.node_slots, trav.nodes,
                  100.0 * trav.prims / std::max(1ull, trav.prim_slots), trav.prims,
                  100.0 * trav.service_lanes / std::max(1ull, trav.service_slots), trav.service_lanes);
+  if (getenv("RTMI_VERBOSE") && trav.node_slots)
+    std::fprintf(stderr, "rtmi: lanes sitting out, %% of the phase's lane slots: node steps -- finished %.1f, no ray %.1f, second leaf %.1f, "
+                 "walk done with a leaf parked %.1f, leaf reached inside the group %.1f; triangle steps -- walking %.1f, finished %.1f, no ray %.1f\n",
+                 100.0 * trav.idle[0] / trav.node_slots, 100.0 * trav.idle[1] / trav.node_slots, 100.0 * trav.idle[2] / trav.node_slots,
+                 100.0 * trav.idle[3] / trav.node_slots, 100.0 * trav.idle[7] / trav.node_slots, 100.0 * trav.idle[4] / std::max(1ull, trav.prim_slots),
+                 100.0 * trav.idle[5] / std::max(1ull, trav.prim_slots), 100.0 * trav.idle[6] / std::max(1ull, trav.prim_slots));
   return RTMI_OK;
 }
 

@@ -49,8 +49,11 @@ def mean(k, c):
 
 res = json.loads(out.read_text()) if out.exists() else {}
 res[key] = {}
+# hash of raytracing_amd/csrc as it was on the GPU box when the passes ran (tools/profile_bench.sh writes it)
+stamp = Path(prof) / "source_hash.txt"
+source_hash = stamp.read_text().strip() if stamp.exists() else None
 for k in vals:
-    e = {"source": prof, "launches_profiled": max(len(v) for v in vals[k].values())}
+    e = {"source": prof, "source_hash": source_hash, "launches_profiled": max(len(v) for v in vals[k].values())}
     fetch, write = mean(k, "FETCH_SIZE"), mean(k, "WRITE_SIZE")
     if fetch is not None and write is not None:
         e["hbm_read_bytes_per_launch"] = 2.0 * 1024.0 * fetch

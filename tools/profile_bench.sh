@@ -5,6 +5,7 @@
 set -u
 out=gpurun_out/$1; shift
 mkdir -p "$out"
+python3 tools/source_hash.py > "$out/source_hash.txt"    # what was profiled: bench.py compares it with what it times
 export TMPDIR=/tmp
 run() { # name, rocprof args...
   local name=$1; shift
