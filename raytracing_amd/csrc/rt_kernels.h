@@ -29,20 +29,27 @@ struct PathQueue {
   RTMI_Q_ARRAY(double2, o_xy, 0)          // origin x, y
   RTMI_Q_ARRAY(double2, oz_dx, 16)        // origin z, direction x
   RTMI_Q_ARRAY(double2, d_yz, 32)         // direction y, z
-  // x = y * width + x of the pixel (Philox counter word 0), y = sample (Philox counter word 1), z = slot (where this
-  // path's contribution goes), w = ray casts the path may still make (the reference's `iteraciones`)
-  RTMI_Q_ARRAY(uint4, ids, 48)
   // closest mesh hit of the entry's ray, used by the two-kernel pipeline: hit_obj is cleared when the entry is
   // created (RT_MISS: no mesh was hit), the rest is filled in by traverse_kernel.
   // x = t as the reference reports it (what objects are compared by), y = Moller-Trumbore's t along the re-normalised
   // ray (places the hit point)
-  RTMI_Q_ARRAY(double2, hit_t_raw, 64)
-  RTMI_Q_ARRAY(uint2, hit_prim_slot, 80)  // file-order triangle index, position of that triangle in leaf order
-  RTMI_Q_ARRAY(uint32_t, hit_obj, 88)
-  RTMI_Q_ARRAY(uint4, chain0, 92)         // spectrum-table rows picked up at hits 0..15, one byte each (92 E is a multiple of 16: E is one of 64)
-  RTMI_Q_ARRAY(uint4, chain1, 108)        // hits 16..31, only when deep
+  RTMI_Q_ARRAY(double2, hit_t_raw, 48)
+  RTMI_Q_ARRAY(uint2, hit_prim_slot, 64)  // file-order triangle index, position of that triangle in leaf order
+  // Where the path's contribution goes. It also names the path: slot = sample_local * n_local_pixels + local pixel, from
+  // which the pixel and sample (the Philox counter words) are recomputed where a path draws random numbers. How many ray
+  // casts a path may still make is not stored either: every path of queue level k has made k.
+  RTMI_Q_ARRAY(uint32_t, slot, 72)
+  RTMI_Q_ARRAY(uint32_t, hit_obj, 76)
+  // Spectrum-table rows picked up at the path's hits, one byte each, as eight arrays of one word (hits 4w .. 4w + 3 in
+  // word w): a path of level k has k hits behind it, so a level reads and writes only its first ceil(k / 4) words -- one
+  // word where most of the paths are (levels 1 to 4). Words 4..7 exist only when `deep`.
+#if defined(__HIPCC__)
+  __host__ __device__ __forceinline__ uint32_t* chain_word(uint32_t w) const { return reinterpret_cast<uint32_t*>(base + entries * uint64_t(80 + 4 * w)); }
+#else
+  uint32_t* chain_word(uint32_t w) const { return reinterpret_cast<uint32_t*>(base + entries * uint64_t(80 + 4 * w)); }
+#endif
 #undef RTMI_Q_ARRAY
-  static constexpr uint64_t bytes_per_entry(bool deep_) { return deep_ ? 124 : 108; }
+  static constexpr uint64_t bytes_per_entry(bool deep_) { return deep_ ? 112 : 96; }
 };
 
 constexpr int kBlock = 256;            // 4 waves of 64
@@ -139,7 +146,8 @@ hipError_t upload_constants(const SpectrumTables& t);
 void launch_primary(const DevScene& sc, const BatchDesc& b, PathQueue out, uint32_t* out_counts, uint32_t region_entries,
                     TraceOutputs o, TraversalCounters* counters, hipStream_t s);
 // Bounce k > 0: consumes the paths of `in` (fill counters in_counts), at most max_in in total.
-void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const uint32_t* in_counts, uint32_t max_in,
+// level: the queue level of `in` (its paths have made `level` ray casts).
+void launch_bounce(const DevScene& sc, const BatchDesc& b, uint32_t level, PathQueue in, const uint32_t* in_counts, uint32_t max_in,
                    PathQueue out, uint32_t* out_counts, uint32_t region_entries, TraceOutputs o,
                    TraversalCounters* counters, hipStream_t s);
 // Two-kernel pipeline, used when the scene has meshes. BVH traversal lengths differ by an order of
@@ -165,8 +173,8 @@ struct LevelCounts { uint32_t* mesh; uint32_t* other; };
 // Rays of level 0 of a camera batch all start at the camera's focus; their entries hold only a direction.
 struct FixedOrigin { double x, y, z; bool fixed; };
 void launch_generate(const DevScene& sc, const BatchDesc& b, PathQueue q, uint32_t region_entries, MeshList mesh, hipStream_t s);
-// start: the paths are level 0 (max_in of them, recreated from their index); otherwise they are read from `in`
-void launch_shade(const DevScene& sc, const BatchDesc& b, bool start, PathQueue in, LevelCounts in_counts, uint32_t max_in,
+// level 0: the paths (max_in of them) are recreated from their index; otherwise they are read from `in`, queue level `level`
+void launch_shade(const DevScene& sc, const BatchDesc& b, uint32_t level, PathQueue in, LevelCounts in_counts, uint32_t max_in,
                   PathQueue out, LevelCounts out_counts, uint32_t region_entries, TraceOutputs o, hipStream_t s);
 void launch_traverse(const DevScene& sc, PathQueue q, MeshList mesh, uint32_t max_in, uint32_t region_entries, FixedOrigin origin,
                      TraversalCounters* counters, hipStream_t s);

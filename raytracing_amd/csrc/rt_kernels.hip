@@ -705,12 +705,15 @@ __device__ __forceinline__ bool dielectric_direction(V3 i, V3 nf, bool entering,
 
 // ------------------------------------------------------------------------------- queues
 
-__device__ __forceinline__ void queue_store(const PathQueue& q, uint32_t at, V3 o, V3 d, uint32_t pixel, uint32_t sample,
-                                            uint32_t slot, uint32_t remaining, const Chain& chain, bool deep) {
+// words of the chain a path of queue level `level` carries: one byte per hit it has behind it
+__device__ __forceinline__ uint32_t chain_words(uint32_t level) { return (level + 3u) >> 2; }
+
+__device__ __forceinline__ void queue_store(const PathQueue& q, uint32_t at, V3 o, V3 d, uint32_t slot, const Chain& chain, uint32_t n_words) {
   q.o_xy()[at] = make_double2(o.x, o.y); q.oz_dx()[at] = make_double2(o.z, d.x); q.d_yz()[at] = make_double2(d.y, d.z);
-  q.ids()[at] = make_uint4(pixel, sample, slot, remaining);
-  q.chain0()[at] = chain.a;
-  if (deep) q.chain1()[at] = chain.b;
+  q.slot()[at] = slot;
+  const uint32_t w[8] = {chain.a.x, chain.a.y, chain.a.z, chain.a.w, chain.b.x, chain.b.y, chain.b.z, chain.b.w};
+#pragma unroll
+  for (uint32_t k = 0; k < 8; ++k) if (k < n_words) q.chain_word(k)[at] = w[k];   // n_words is the same for the whole launch
 }
 
 // local pixel of a batch -> image coordinates. Tiles are numbered x-major as the reference
@@ -776,31 +779,38 @@ __device__ __forceinline__ uint32_t find_region(const uint32_t* s_prefix, uint32
 
 // ------------------------------------------------------------------------------- pieces of a bounce
 
-// What one path brings into a bounce.
+// What one path brings into a bounce. pixel and sample are the Philox counter words of the path's random numbers; a
+// path that comes out of a queue recomputes them from its slot when it needs them (path_ids).
 struct PathState {
   V3 o, d;
-  uint32_t pixel, sample, slot, remaining;
+  uint32_t pixel, sample, slot;
   Chain chain;
 };
+
+// Pixel (y * width + x) and sample of the path whose contribution slot is `slot`.
+__device__ __forceinline__ bool path_ids(const BatchDesc& b, uint32_t slot, uint32_t& pixel, uint32_t& sample, uint32_t& x, uint32_t& y) {
+  if (b.rays) { pixel = b.pixel_base + slot; sample = b.sample0; x = y = 0; return true; }
+  const uint32_t sample_local = fast_div(slot, b.by_local_pixels);
+  const uint32_t lp = slot - sample_local * b.n_local_pixels;
+  sample = b.sample0 + sample_local;
+  const bool inside = local_pixel_to_xy(b, lp, x, y);
+  pixel = y * b.cam.width + x;
+  return inside;
+}
 
 // Path `idx` of a batch at its start: the camera ray through its jittered pixel position
 // (evaluate_pixel_sample, src/integrators/integrator.rs:130-135 + Camera::get_ray, src/camera.rs:80-84),
 // or the caller's ray. Returns false for a pixel that the last tiles hang over the image edge.
 __device__ __forceinline__ bool start_path(const BatchDesc& b, uint32_t idx, PathState& s) {
   s.slot = idx;
-  s.remaining = b.integrator == RT_INT_RANDOM_WALK ? b.max_depth : 0;
   s.chain.a = make_uint4(0, 0, 0, 0); s.chain.b = make_uint4(0, 0, 0, 0);
+  uint32_t x, y;
+  const bool inside = path_ids(b, idx, s.pixel, s.sample, x, y);
   if (b.rays) {
     s.o = ld3(b.rays + size_t(idx) * 6); s.d = ld3(b.rays + size_t(idx) * 6 + 3);
-    s.pixel = b.pixel_base + idx; s.sample = b.sample0;
     return true;
   }
-  const uint32_t sample_local = fast_div(idx, b.by_local_pixels);
-  const uint32_t lp = idx - sample_local * b.n_local_pixels;
-  s.sample = b.sample0 + sample_local;
-  uint32_t x, y;
-  if (!local_pixel_to_xy(b, lp, x, y)) return false;
-  s.pixel = y * b.cam.width + x;
+  if (!inside) return false;
   double u0, u1;
   uniform_pair(b.seed, s.pixel, s.sample, 0, 0, u0, u1);
   const double fi = double(x) + u0 - 0.5, fj = double(y) + u1 - 0.5;
@@ -812,14 +822,16 @@ __device__ __forceinline__ bool start_path(const BatchDesc& b, uint32_t idx, Pat
   return true;
 }
 
-__device__ __forceinline__ void load_path(const PathQueue& q, uint32_t idx, bool deep, PathState& s) {
+__device__ __forceinline__ void load_path(const PathQueue& q, uint32_t idx, uint32_t n_words, PathState& s) {
   const double2 o_xy = q.o_xy()[idx], oz_dx = q.oz_dx()[idx], d_yz = q.d_yz()[idx];
   s.o = mk(o_xy.x, o_xy.y, oz_dx.x);
   s.d = mk(oz_dx.y, d_yz.x, d_yz.y);
-  const uint4 ids = q.ids()[idx];
-  s.pixel = ids.x; s.sample = ids.y; s.slot = ids.z; s.remaining = ids.w;
-  s.chain.a = q.chain0()[idx];
-  s.chain.b = deep ? q.chain1()[idx] : make_uint4(0, 0, 0, 0);
+  s.slot = q.slot()[idx];
+  s.pixel = s.sample = 0;
+  uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (uint32_t k = 0; k < 8; ++k) if (k < n_words) w[k] = q.chain_word(k)[idx];
+  s.chain.a = make_uint4(w[0], w[1], w[2], w[3]); s.chain.b = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
 // What shading a hit decides.
@@ -838,9 +850,14 @@ struct Shaded {
 // EXT: the scene has glossy or dielectric materials (extensions). Their code (a binary64 pow above all) needs
 // some 40 registers more than the reference's three material types, which costs every scene a resident wave
 // per SIMD, so kernels are instantiated with and without it.
-template <bool EXT>
+// level: ray casts the path has made before this one (0 = this is its first intersection). IDS: s.pixel and s.sample are
+// valid (the path was started in this kernel); otherwise they are recomputed from the slot where random numbers are drawn.
+template <bool EXT, bool IDS>
 __device__ __forceinline__ Shaded shade_hit(const DevScene& sc, const BatchDesc& b, const TraceOutputs& o, bool found, Hit& hit,
-                                            bool first_hit, PathState& s) {
+                                            uint32_t level, PathState& s) {
+  const bool first_hit = level == 0;
+  // ray casts the path may still make, this one included (the reference's `iteraciones`)
+  const uint32_t remaining = b.integrator == RT_INT_RANDOM_WALK ? b.max_depth - level : 0;
   Shaded r;
   r.alive = false; r.emits = false; r.emit_info = 0; r.no = s.o; r.nd = s.d;
   float xyz[3];
@@ -859,39 +876,41 @@ __device__ __forceinline__ Shaded shade_hit(const DevScene& sc, const BatchDesc&
     } else if (b.integrator == RT_INT_NORMAL) {
       normal_sample(hit.n, xyz, spectrum_out);   // un-turned geometric normal (src/integrators/normal.rs:50)
       contributes = true;
-    } else if (s.remaining != 0) {               // depth == 0 returns black after intersecting (random_walk.rs:68-70)
+    } else if (remaining != 0) {                 // depth == 0 returns black after intersecting (random_walk.rs:68-70)
       const bool entering = dot(hit.n, s.d) < 0.0;   // against the outward normal (dielectric only)
       if (!first_hit && dot(hit.n, s.d) > 0.0) hit.n = neg(hit.n);
-      const uint32_t hit_index = b.max_depth - s.remaining;
+      const uint32_t hit_index = level;
       if (m.type == RT_MAT_EMITTER) {            // src/scene.rs:56-62
         if (m.present & RT_HAS_EMITTED) {
           if (o.emit_counts) { r.emits = true; r.emit_info = uint32_t(m.emitted) | (hit_index << 8); }
           else { emit_sample(sc.spectra, m.emitted, s.chain, hit_index, xyz, spectrum_out); contributes = true; }
         }
-      } else if (s.remaining > 1) {
+      } else if (remaining > 1) {
         // the continuing materials choose a direction, a side of the surface and a factor; the new ray is formed once
         // for all of them, so a wave with several materials runs the normalisation once
         V3 dir = s.d, side = hit.n;
         uint32_t factor = (m.present & RT_HAS_SPECULAR) ? uint32_t(m.specular) : uint32_t(RT_NO_SPECTRUM);
         bool continues = true;
+        uint32_t pixel = s.pixel, sample = s.sample;
+        if (!IDS && (m.type != RT_MAT_SPECULAR)) { uint32_t x, y; path_ids(b, s.slot, pixel, sample, x, y); }
         if (m.type == RT_MAT_LAMBERTIAN) {       // src/scene.rs:63-79
           continues = (m.present & RT_HAS_AMBIENT) != 0;
           if (continues) {
             double r1, r2;
-            uniform_pair(b.seed, s.pixel, s.sample, hit_index, 1, r1, r2);
+            uniform_pair(b.seed, pixel, sample, hit_index, 1, r1, r2);
             dir = cosine_direction(hit.n, r1, r2);
             factor = m.ambient;
           }
         } else if (EXT && m.type == RT_MAT_GLOSSY) {      // extension: Phong lobe about the mirror direction
           const V3 axis = normalize(s.d - hit.n * (2.0 * dot(s.d, hit.n)));
           double r1, r2;
-          uniform_pair(b.seed, s.pixel, s.sample, hit_index, 1, r1, r2);
+          uniform_pair(b.seed, pixel, sample, hit_index, 1, r1, r2);
           dir = phong_lobe_direction(axis, double(m.ns), r1, r2);
           continues = dot(dir, hit.n) > 0.0;     // a sample under the surface is absorbed
         } else if (EXT && m.type == RT_MAT_DIELECTRIC) {  // extension: smooth dielectric with Schlick's reflectance
           const V3 nf = dot(hit.n, s.d) > 0.0 ? neg(hit.n) : hit.n;
           double u0, u1;
-          uniform_pair(b.seed, s.pixel, s.sample, hit_index, 1, u0, u1);
+          uniform_pair(b.seed, pixel, sample, hit_index, 1, u0, u1);
           const bool reflected = dielectric_direction(s.d, nf, entering, double(m.ni), u0, dir);
           side = reflected ? nf : neg(nf);       // a refracted ray starts on the far side
         } else {                                 // Specular, src/scene.rs:80-112
@@ -1079,7 +1098,7 @@ __device__ __forceinline__ bool queue_position2(const ChunkMap& m, uint32_t regi
 // which the compiler loads once at entry and then has to keep in -- and spill from -- the 100-odd scalar registers.
 struct BounceArgs {
   DevScene sc; BatchDesc b; PathQueue in; const uint32_t* in_counts; uint32_t region_entries; PathQueue out;
-  uint32_t* out_counts; TraceOutputs o; TraversalCounters* counters;
+  uint32_t* out_counts; TraceOutputs o; TraversalCounters* counters; uint32_t level;
 };
 typedef const __attribute__((address_space(4))) BounceArgs* BounceArgsPtr;
 
@@ -1101,6 +1120,7 @@ bounce_kernel(BounceArgs a) {
   uint32_t* __restrict__ out_counts = ap->out_counts;
   const uint32_t region_entries = ap->region_entries;
   TraversalCounters* counters = ap->counters;
+  const uint32_t level = PRIMARY ? 0u : ap->level;   // ray casts the paths of `in` have made
   extern __shared__ uint4 lds_dynamic[];
   __shared__ uint32_t s_chunk_prefix[kShards + 1];  // chunks of kBlock paths before each input region
   __shared__ uint32_t s_region_fill[kShards];
@@ -1118,24 +1138,24 @@ bounce_kernel(BounceArgs a) {
     if (PRIMARY) { idx = chunk * kBlock + threadIdx.x; active = idx < n_start; }
     else active = queue_position(s_chunk_prefix, s_region_fill, region_entries, chunk, idx);
     PathState ps;
-    ps.o = mk(0, 0, 0); ps.d = mk(1, 0, 0); ps.pixel = ps.sample = ps.slot = ps.remaining = 0;
+    ps.o = mk(0, 0, 0); ps.d = mk(1, 0, 0); ps.pixel = ps.sample = ps.slot = 0;
     ps.chain.a = make_uint4(0, 0, 0, 0); ps.chain.b = make_uint4(0, 0, 0, 0);
     if (active) {
       if (PRIMARY) active = start_path(b, idx, ps);
-      else load_path(in, idx, deep, ps);
+      else load_path(in, idx, chain_words(level), ps);
     }
     Shaded sh;
     sh.alive = false; sh.emits = false; sh.emit_info = 0; sh.no = ps.o; sh.nd = ps.d;
     if (active) {
       Hit hit;
       const bool found = closest_hit<RULE, COUNT, MESH>(sc, node_words, ps.o, ps.d, stack, hit, n_nodes, n_prims);
-      sh = shade_hit<EXT>(sc, b, o, found, hit, PRIMARY, ps);
+      sh = shade_hit<EXT, PRIMARY>(sc, b, o, found, hit, level, ps);
     }
     const Appends ap3 = reserve_appends(o.emit_counts, out_counts, out_counts, region_entries, chunk, sh.emits, sh.alive, false);
     emit_or_append(sc, o, chunk, deep, ap3, sh.emits, sh.emit_info, ps.slot, ps.chain);
     const uint32_t within = sh.alive ? place_in(ap3.first_mask, ap3.first_start, region_entries) : RT_MISS;
     if (within != RT_MISS)
-      queue_store(out, (chunk % kShards) * region_entries + within, sh.no, sh.nd, ps.pixel, ps.sample, ps.slot, ps.remaining - 1, ps.chain, deep);
+      queue_store(out, (chunk % kShards) * region_entries + within, sh.no, sh.nd, ps.slot, ps.chain, chain_words(level + 1));
   }
 
   if (COUNT) {
@@ -1237,7 +1257,7 @@ generate_camera_kernel(DevScene sc, BatchDesc b, PathQueue q, uint32_t region_en
 
 struct ShadeArgs {
   DevScene sc; BatchDesc b; PathQueue in; LevelCounts in_counts; uint32_t region_entries; PathQueue out;
-  LevelCounts out_counts; TraceOutputs o;
+  LevelCounts out_counts; TraceOutputs o; uint32_t level;
 };
 typedef const __attribute__((address_space(4))) ShadeArgs* ShadeArgsPtr;
 
@@ -1259,15 +1279,17 @@ __device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
   // wave reserves its appends -- when little else is live in registers -- so its trip from memory overlaps the atomic's
   // round trip, the stores and the top of the next iteration instead of standing at the head of it.
   constexpr bool kAhead = !START && RT_PREFETCH;
+  const uint32_t level = START ? 0u : ap->level;        // ray casts the paths of `in` have made
+  const uint32_t words_in = chain_words(level);
   PathState ps_ahead;
-  ps_ahead.o = mk(0, 0, 0); ps_ahead.d = mk(1, 0, 0); ps_ahead.pixel = ps_ahead.sample = ps_ahead.slot = ps_ahead.remaining = 0;
+  ps_ahead.o = mk(0, 0, 0); ps_ahead.d = mk(1, 0, 0); ps_ahead.pixel = ps_ahead.sample = ps_ahead.slot = 0;
   ps_ahead.chain.a = make_uint4(0, 0, 0, 0); ps_ahead.chain.b = make_uint4(0, 0, 0, 0);
   uint32_t idx_ahead = 0, obj_ahead = RT_MISS;
   bool active_ahead = false;
   if (kAhead && blockIdx.x < n_chunks) {
     const PathQueue& in0 = *(const PathQueue*)&ap->in;
     active_ahead = queue_position2(chunk_map, ap->region_entries, blockIdx.x, idx_ahead);
-    if (active_ahead) { load_path(in0, idx_ahead, ap->b.max_depth > 16, ps_ahead); obj_ahead = in0.hit_obj()[idx_ahead]; }
+    if (active_ahead) { load_path(in0, idx_ahead, words_in, ps_ahead); obj_ahead = in0.hit_obj()[idx_ahead]; }
   }
 
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
@@ -1286,7 +1308,7 @@ __device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
     else if (kAhead) { idx = idx_ahead; active = active_ahead; }
     else active = queue_position2(chunk_map, region_entries, chunk, idx);
     PathState ps;
-    ps.o = mk(0, 0, 0); ps.d = mk(1, 0, 0); ps.pixel = ps.sample = ps.slot = ps.remaining = 0;
+    ps.o = mk(0, 0, 0); ps.d = mk(1, 0, 0); ps.pixel = ps.sample = ps.slot = 0;
     ps.chain.a = make_uint4(0, 0, 0, 0); ps.chain.b = make_uint4(0, 0, 0, 0);
     Shaded sh;
     sh.alive = false; sh.emits = false; sh.emit_info = 0; sh.no = ps.o; sh.nd = ps.d;
@@ -1295,7 +1317,7 @@ __device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
       if (active) ps = ps_ahead;
     } else if (active) {
       if (START) active = start_path(b, idx, ps);
-      else load_path(in, idx, deep, ps);
+      else load_path(in, idx, words_in, ps);
     }
     if (active) {
       const V3 dn = normalize(ps.d);   // src/geometry/ray.rs:45
@@ -1316,8 +1338,7 @@ __device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
       }
       const bool found = hit.obj != RT_MISS;
       if (found) hit_surface(sc, hit.obj, ps.o, ps.d, dn, hit.t, t_raw, tri_slot, hit.p, hit.n, hit.mat);
-      const bool first_hit = b.integrator != RT_INT_RANDOM_WALK || ps.remaining == b.max_depth;
-      sh = shade_hit<EXT>(sc, b, o, found, hit, first_hit, ps);
+      sh = shade_hit<EXT, START>(sc, b, o, found, hit, level, ps);
     }
     // a level keeps its paths in two classes per region: those whose ray meets a mesh's box fill it from the front,
     // the others from the back (see number_chunks2)
@@ -1327,7 +1348,7 @@ __device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
       active_ahead = false;
       if (next_chunk < n_chunks) {
         active_ahead = queue_position2(chunk_map, region_entries, next_chunk, idx_ahead);
-        if (active_ahead) { load_path(in, idx_ahead, deep, ps_ahead); obj_ahead = in.hit_obj()[idx_ahead]; }
+        if (active_ahead) { load_path(in, idx_ahead, words_in, ps_ahead); obj_ahead = in.hit_obj()[idx_ahead]; }
       }
     }
     const Appends ap3 = reserve_appends(o.emit_counts, out_counts.mesh, out_counts.other, region_entries, chunk, sh.emits, meets_mesh,
@@ -1340,7 +1361,7 @@ __device__ __forceinline__ void shade_paths(ShadeArgsPtr ap) {
       if (within != RT_MISS) at = (chunk % kShards) * region_entries + (meets_mesh ? within : region_entries - 1u - within);
     }
     if (at != RT_MISS) {
-      queue_store(out, at, sh.no, sh.nd, ps.pixel, ps.sample, ps.slot, ps.remaining - 1, ps.chain, deep);
+      queue_store(out, at, sh.no, sh.nd, ps.slot, ps.chain, chain_words(level + 1));
       out.hit_obj()[at] = RT_MISS;
     }
   }
@@ -1772,17 +1793,17 @@ void launch_primary(const DevScene& sc, const BatchDesc& b, PathQueue out, uint3
   const dim3 grid(grid_for(n));
   const size_t lds = size_t(sc.stack_entries) * kBlock * sizeof(uint32_t);
   PathQueue none{};
-  const BounceArgs a{sc, b, none, nullptr, region_entries, out, out_counts, o, counters};
+  const BounceArgs a{sc, b, none, nullptr, region_entries, out, out_counts, o, counters, 0};
   RTMI_DISPATCH(bounce_kernel, true, a);
 }
 
-void launch_bounce(const DevScene& sc, const BatchDesc& b, PathQueue in, const uint32_t* in_counts, uint32_t max_in,
+void launch_bounce(const DevScene& sc, const BatchDesc& b, uint32_t level, PathQueue in, const uint32_t* in_counts, uint32_t max_in,
                    PathQueue out, uint32_t* out_counts, uint32_t region_entries, TraceOutputs o,
                    TraversalCounters* counters, hipStream_t s) {
   if (max_in == 0) return;
   const dim3 grid(grid_for(size_t(max_in) + size_t(kShards) * kBlock));
   const size_t lds = size_t(sc.stack_entries) * kBlock * sizeof(uint32_t);
-  const BounceArgs a{sc, b, in, in_counts, region_entries, out, out_counts, o, counters};
+  const BounceArgs a{sc, b, in, in_counts, region_entries, out, out_counts, o, counters, level};
   RTMI_DISPATCH(bounce_kernel, false, a);
 }
 
@@ -1793,12 +1814,13 @@ void launch_generate(const DevScene& sc, const BatchDesc& b, PathQueue q, uint32
   else hipLaunchKernelGGL(generate_camera_kernel, dim3(grid_for(b.n_local_pixels)), kBlock, 0, s, sc, b, q, region_entries, mesh);
 }
 
-void launch_shade(const DevScene& sc, const BatchDesc& b, bool start, PathQueue in, LevelCounts in_counts, uint32_t max_in,
+void launch_shade(const DevScene& sc, const BatchDesc& b, uint32_t level, PathQueue in, LevelCounts in_counts, uint32_t max_in,
                   PathQueue out, LevelCounts out_counts, uint32_t region_entries, TraceOutputs o, hipStream_t s) {
   if (max_in == 0) return;
+  const bool start = level == 0;
   const dim3 grid(grid_for(size_t(max_in) + (start ? 0 : 2 * size_t(kShards) * kBlock)));
   const int sel = (start ? 2 : 0) | (sc.extension_materials ? 1 : 0);
-  const ShadeArgs a{sc, b, in, in_counts, region_entries, out, out_counts, o};
+  const ShadeArgs a{sc, b, in, in_counts, region_entries, out, out_counts, o, level};
   switch (sel) {
     case 0: hipLaunchKernelGGL(shade_kernel, grid, kBlock, 0, s, a); break;
     case 1: hipLaunchKernelGGL((shade_extended_kernel<false>), grid, kBlock, 0, s, a); break;

@@ -402,7 +402,7 @@ int run_batch(rtmi_scene* sc, const Workspace& ws, const BatchDesc& b, size_t n_
     ++launches;
     for (uint32_t k = 1; k < depth; ++k) {
       clock.begin();
-      launch_bounce(sc->dev, b, ws.queue[(k - 1) & 1], level_counts(k), uint32_t(n_paths), ws.queue[k & 1],
+      launch_bounce(sc->dev, b, k, ws.queue[(k - 1) & 1], level_counts(k), uint32_t(n_paths), ws.queue[k & 1],
                     level_counts(k + 1), region_entries, o, counters, stream);
       clock.end();
       ++launches;
@@ -424,7 +424,7 @@ int run_batch(rtmi_scene* sc, const Workspace& ws, const BatchDesc& b, size_t n_
       launch_traverse(sc->dev, ws.queue[k & 1], mesh_list(k), uint32_t(n_paths), region_entries, origin, counters, stream);
       clock.end();
       clock.begin();
-      launch_shade(sc->dev, b, k == 0, ws.queue[k & 1], both(k), uint32_t(n_paths), ws.queue[(k + 1) & 1], both(k + 1), region_entries, o,
+      launch_shade(sc->dev, b, k, ws.queue[k & 1], both(k), uint32_t(n_paths), ws.queue[(k + 1) & 1], both(k + 1), region_entries, o,
                    stream);
       clock.end();
       launches += 2;
