@@ -213,7 +213,13 @@ QuantizedNodes quantize_nodes(const BvhBuild& build, int format) {
     }
   double widest = 0.0;
   for (int k = 0; k < 3; ++k) if (hi[k] >= lo[k]) widest = std::max(widest, hi[k] - lo[k]);
-  for (int k = 0; k < 3; ++k) quant_grid_axis(lo[k], hi[k], widest, &q.grid_lo[k], &q.grid_step[k]);
+  const bool half_planes = format == RT_NODES_SMALL && RT_SMALL_F16;
+  double reach = 0.0;
+  for (int k = 0; k < 3; ++k) if (hi[k] >= lo[k]) reach = std::max(reach, std::max(std::fabs(lo[k]), std::fabs(hi[k])));
+  for (int k = 0; k < 3; ++k) {
+    if (half_planes) half_grid_axis(reach, &q.grid_lo[k], &q.grid_step[k]);
+    else quant_grid_axis(lo[k], hi[k], widest, &q.grid_lo[k], &q.grid_step[k]);
+  }
   const uint32_t w4 = node_words4(format);
   q.words.assign(build.nodes.size() * w4, RtWord4{0, 0, 0, 0});
   for (size_t i = 0; i < build.nodes.size(); ++i) {
@@ -223,8 +229,13 @@ QuantizedNodes quantize_nodes(const BvhBuild& build, int format) {
       const bool none = (c ? n.ref1 : n.ref0) == RT_REF_NONE;
       const float* l = c ? n.lo1 : n.lo0; const float* h = c ? n.hi1 : n.hi0;
       for (int k = 0; k < 3; ++k) {
-        b[c * 6 + k] = none ? 65535u : quant_level_lo(double(l[k]), q.grid_lo[k], q.grid_step[k]);   // an empty slot's box is inside out
-        b[c * 6 + 3 + k] = none ? 0u : quant_level_hi(double(h[k]), q.grid_lo[k], q.grid_step[k]);
+        if (half_planes) {   // an empty slot's box is inside out
+          b[c * 6 + k] = none ? 0x7BFFu : half_plane_lo(double(l[k]), q.grid_step[k]);
+          b[c * 6 + 3 + k] = none ? 0xFBFFu : half_plane_hi(double(h[k]), q.grid_step[k]);
+        } else {
+          b[c * 6 + k] = none ? 65535u : quant_level_lo(double(l[k]), q.grid_lo[k], q.grid_step[k]);
+          b[c * 6 + 3 + k] = none ? 0u : quant_level_hi(double(h[k]), q.grid_lo[k], q.grid_step[k]);
+        }
       }
     }
     pack_node(&q.words[i * w4], format, b, n.ref0, n.ref1, n.min_index0, n.min_index1);

@@ -252,8 +252,13 @@ __global__ void __launch_bounds__(kThreads) emit_nodes_kernel(Tree t, Fit f, con
       // binary32 box relative to the mesh centre that contains the binary64 one: pad, then round outward
       const float lo = __double2float_rd((f.box[size_t(unit) * 6 + k] - fr.center[k]) - fr.pad);
       const float hi = __double2float_ru((f.box[size_t(unit) * 6 + 3 + k] - fr.center[k]) + fr.pad);
-      levels[c * 6 + k] = quant_level_lo(double(lo), fr.grid_lo[k], fr.grid_step[k]);
-      levels[c * 6 + 3 + k] = quant_level_hi(double(hi), fr.grid_lo[k], fr.grid_step[k]);
+      if (format == RT_NODES_SMALL && RT_SMALL_F16) {
+        levels[c * 6 + k] = half_plane_lo(double(lo), fr.grid_step[k]);
+        levels[c * 6 + 3 + k] = half_plane_hi(double(hi), fr.grid_step[k]);
+      } else {
+        levels[c * 6 + k] = quant_level_lo(double(lo), fr.grid_lo[k], fr.grid_step[k]);
+        levels[c * 6 + 3 + k] = quant_level_hi(double(hi), fr.grid_lo[k], fr.grid_step[k]);
+      }
     }
   }
   pack_node(words + size_t(compact[i]) * w4, format, levels, ref[0], ref[1], mins[0], mins[1]);
@@ -336,8 +341,11 @@ hipError_t build_lbvh(const double* host_vertices, uint32_t n, int format, LbvhO
     flo[k] = double(l); fhi[k] = double(h);
     widest = std::max(widest, fhi[k] - flo[k]);
   }
+  double reach = 0.0;
+  for (int k = 0; k < 3; ++k) reach = std::max(reach, std::max(std::fabs(flo[k]), std::fabs(fhi[k])));
   for (int k = 0; k < 3; ++k) {
-    quant_grid_axis(flo[k], fhi[k], widest, &out->grid_lo[k], &out->grid_step[k]);
+    if (format == RT_NODES_SMALL && RT_SMALL_F16) half_grid_axis(reach, &out->grid_lo[k], &out->grid_step[k]);
+    else quant_grid_axis(flo[k], fhi[k], widest, &out->grid_lo[k], &out->grid_step[k]);
     fr.grid_lo[k] = out->grid_lo[k]; fr.grid_step[k] = out->grid_step[k];
   }
 

@@ -319,13 +319,29 @@ __device__ __forceinline__ QuantRay make_quant_ray(const BoxRay& r, const DevObj
   q.lx = (ob.grid_lo[0] - (r.ox + r.delta)) * r.ix; q.hx = (ob.grid_lo[0] - (r.ox - r.delta)) * r.ix;
   q.ly = (ob.grid_lo[1] - (r.oy + r.delta)) * r.iy; q.hy = (ob.grid_lo[1] - (r.oy - r.delta)) * r.iy;
   q.lz = (ob.grid_lo[2] - (r.oz + r.delta)) * r.iz; q.hz = (ob.grid_lo[2] - (r.oz - r.delta)) * r.iz;
+  // A direction component that is zero (or so small that its reciprocal overflows or nearly does) makes these products
+  // infinite, and a plane distance "finite * inf + (-+inf)" is then an infinity or a NaN depending on the plane's sign --
+  // which would reject boxes the ray runs inside of. On such an axis every plane pair is placed at (-inf, +inf): the axis
+  // never decides, which is conservative.
+  if (!(fabsf(r.ix) < 0x1.0p40f)) { q.sx = 0.0f; q.lx = -INFINITY; q.hx = INFINITY; }
+  if (!(fabsf(r.iy) < 0x1.0p40f)) { q.sy = 0.0f; q.ly = -INFINITY; q.hy = INFINITY; }
+  if (!(fabsf(r.iz) < 0x1.0p40f)) { q.sz = 0.0f; q.lz = -INFINITY; q.hz = INFINITY; }
   return q;
 }
 
 struct Children { bool h0, h1; float tn0, tn1; uint32_t ref0, ref1, min0, min1; };
 
-__device__ __forceinline__ float q_lo16(uint32_t w) { return float(w & 0xFFFFu); }
-__device__ __forceinline__ float q_hi16(uint32_t w) { return float(w >> 16); }
+// The two planes a node word holds, as the binary32 factors of the fused multiply-adds below: integer levels, or (the
+// small format with RT_SMALL_F16) binary16 values, whose conversion the multiply-add instruction does by itself.
+typedef _Float16 HalfPair __attribute__((ext_vector_type(2)));
+template <int FMT> __device__ __forceinline__ float q_lo16(uint32_t w) {
+  if (FMT == RT_NODES_SMALL && RT_SMALL_F16) return float(__builtin_bit_cast(HalfPair, w).x);
+  return float(w & 0xFFFFu);
+}
+template <int FMT> __device__ __forceinline__ float q_hi16(uint32_t w) {
+  if (FMT == RT_NODES_SMALL && RT_SMALL_F16) return float(__builtin_bit_cast(HalfPair, w).y);
+  return float(w >> 16);
+}
 
 // Both children of the node at `np` against the ray: slab tests on the quantised planes (a zero direction component
 // gives +-inf or NaN; fminf/fmaxf drop a NaN operand, which only makes the test more permissive), the final comparison
@@ -335,17 +351,17 @@ __device__ __forceinline__ Children test_children(const uint4* __restrict__ np, 
   const uint4 w0 = np[0], w1 = np[1];
   Children c;
   {
-    const float ax = __builtin_fmaf(q_lo16(w0.x), r.sx, r.lx), bx = __builtin_fmaf(q_hi16(w0.y), r.sx, r.hx);
-    const float ay = __builtin_fmaf(q_hi16(w0.x), r.sy, r.ly), by = __builtin_fmaf(q_lo16(w0.z), r.sy, r.hy);
-    const float az = __builtin_fmaf(q_lo16(w0.y), r.sz, r.lz), bz = __builtin_fmaf(q_hi16(w0.z), r.sz, r.hz);
+    const float ax = __builtin_fmaf(q_lo16<FMT>(w0.x), r.sx, r.lx), bx = __builtin_fmaf(q_hi16<FMT>(w0.y), r.sx, r.hx);
+    const float ay = __builtin_fmaf(q_hi16<FMT>(w0.x), r.sy, r.ly), by = __builtin_fmaf(q_lo16<FMT>(w0.z), r.sy, r.hy);
+    const float az = __builtin_fmaf(q_lo16<FMT>(w0.y), r.sz, r.lz), bz = __builtin_fmaf(q_hi16<FMT>(w0.z), r.sz, r.hz);
     const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
     const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
     c.tn0 = tn; c.h0 = tn <= tf * 1.000002f;
   }
   {
-    const float ax = __builtin_fmaf(q_lo16(w0.w), r.sx, r.lx), bx = __builtin_fmaf(q_hi16(w1.x), r.sx, r.hx);
-    const float ay = __builtin_fmaf(q_hi16(w0.w), r.sy, r.ly), by = __builtin_fmaf(q_lo16(w1.y), r.sy, r.hy);
-    const float az = __builtin_fmaf(q_lo16(w1.x), r.sz, r.lz), bz = __builtin_fmaf(q_hi16(w1.y), r.sz, r.hz);
+    const float ax = __builtin_fmaf(q_lo16<FMT>(w0.w), r.sx, r.lx), bx = __builtin_fmaf(q_hi16<FMT>(w1.x), r.sx, r.hx);
+    const float ay = __builtin_fmaf(q_hi16<FMT>(w0.w), r.sy, r.ly), by = __builtin_fmaf(q_lo16<FMT>(w1.y), r.sy, r.hy);
+    const float az = __builtin_fmaf(q_lo16<FMT>(w1.x), r.sz, r.lz), bz = __builtin_fmaf(q_hi16<FMT>(w1.y), r.sz, r.hz);
     const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
     const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
     c.tn1 = tn; c.h1 = tn <= tf * 1.000002f;

@@ -98,6 +98,11 @@ static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 //   RT_NODES_NEAREST (32 bytes; nearest-hit rule only, which never reads the minimum indices)
 //              word 6 = ref0, word 7 = ref1, as in BvhNode
 //   RT_NODES_WIDE    (48 bytes) words 6-9 = ref0, ref1, min_index0, min_index1, as in BvhNode; words 10-11 unused
+//   With RT_SMALL_F16 the twelve planes of the RT_NODES_SMALL format are binary16 values (coordinate / grid_step, grid_lo = 0,
+//   rounded outward; csrc/bvh_quant.h) in the same positions instead of integer levels.
+#ifndef RT_SMALL_F16
+#define RT_SMALL_F16 1
+#endif
 struct alignas(16) RtWord4 { uint32_t x, y, z, w; };
 enum { RT_NODES_SMALL = 0, RT_NODES_NEAREST = 1, RT_NODES_WIDE = 2 };
 #define RT_SMALL_MAX_TRIS 8188u
