@@ -65,7 +65,9 @@ enum {
 /* rtmi_render_params.flags */
 enum {
   RTMI_FLAG_TIME_KERNELS = 1,    /* bracket every closest-hit kernel with HIP events (adds host syncs) */
-  RTMI_FLAG_COUNT_TRAVERSAL = 2  /* count BVH nodes visited and triangles tested (slower kernel variant) */
+  RTMI_FLAG_COUNT_TRAVERSAL = 2, /* count BVH nodes visited and triangles tested (slower kernel variant) */
+  RTMI_FLAG_EMPTY_SHARE = 4      /* this call's share of the render is empty (a rank beyond the samples of a sample partition):
+                                    the arguments are checked and nothing is rendered */
 };
 
 /* Ray (src/geometry/ray.rs:5-10): direction must be normalised; max_t is always +inf on this path */
@@ -160,9 +162,13 @@ typedef struct rtmi_scene rtmi_scene;
 /* ---- context ---------------------------------------------------------------------------- */
 
 /* Binds a context to GPU `device_id` (-1 = the current HIP device). Replaces nothing in the
- * reference: the reference has no device. max_batch_paths caps the path slots (and so the
- * memory) one render batch uses; 0 = default, 2^27 slots (about 230 bytes of workspace per slot,
- * allocated only up to what a render actually needs). */
+ * reference: the reference has no device. max_batch_paths caps the path slots one render batch uses;
+ * 0 = default, 2^27 slots. A batch needs about 210 bytes of workspace per slot (two path queues, the
+ * traversal list, the emit queue, the per-slot contributions), allocated only up to what a render
+ * actually needs. A render overlaps its batches on up to three internal lanes, each with a workspace
+ * of its own, so a context holds up to 3 x (one batch) of device memory; when that does not fit, the
+ * library first gives up lanes (down to one, with the batch size asked for) and only then, if
+ * max_batch_paths was 0, halves its own default batch. RTMI_LANES=1..4 fixes the lane count. */
 int rtmi_ctx_create(int device_id, uint64_t max_batch_paths, rtmi_ctx** out);
 void rtmi_ctx_destroy(rtmi_ctx* ctx);
 /* Message of the calling thread's most recent failed call ("" if none). */
@@ -224,7 +230,11 @@ int rtmi_render_accumulate(rtmi_scene* scene, const rtmi_camera* cam, const rtmi
 int rtmi_render_accumulate_noalloc(rtmi_scene* scene, const rtmi_camera* cam, const rtmi_render_params* params,
                                    float* dev_xyz_sum, void* stream);
 /* Fills *stats with the counters of the last render_accumulate on `scene` once its stream work
- * has completed (synchronises the stream). */
+ * has completed (synchronises the stream). This is also where a render that had to drop paths (a path-queue region
+ * overflowed: an internal sizing error, never expected) is reported, as RTMI_INTERNAL: rtmi_render_accumulate and
+ * rtmi_render_accumulate_noalloc are asynchronous and return before that can be known. The condition is sticky on the
+ * device until it has been reported once, so collecting the statistics of any later render on the same context still
+ * reports it; rtmi_render and rtmi_multi_render collect them themselves. */
 int rtmi_render_collect_stats(rtmi_scene* scene, void* stream, rtmi_stats* stats);
 /* mean = sum / spp, XYZ -> RGB, clamp, gamma, u8 (src/integrators/integrator.rs:79-90). */
 int rtmi_tonemap(rtmi_ctx* ctx, const float* dev_xyz_sum, uint32_t spp, uint32_t width, uint32_t height,

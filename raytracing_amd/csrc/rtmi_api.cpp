@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -72,7 +73,10 @@ struct DevBuf {
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// Per-render counters, cleared when a render starts; `overflow` (last) is sticky: it is cleared only when the block is
+// allocated, so a render that dropped paths is still reported when the statistics of a later render are collected.
 struct DeviceStats { unsigned long long bounce_segments; TraversalCounters trav; unsigned long long mesh_rays; uint32_t overflow, pad; };
+constexpr size_t kPerRenderStatsBytes = offsetof(DeviceStats, overflow);
 
 }  // namespace
 
@@ -146,6 +150,10 @@ struct rtmi_ctx {
   DevBuf tiles, rays, hits, spectra_out, image;
   bool batch_is_default = true;   // max_batch_paths was not chosen by the caller: it may shrink if memory is short
   bool inline_emit = false;       // RTMI_INLINE_EMIT (read once, when the context is created): no emit queue, for A/B measurements
+  // Fault injection for the tests of the error paths (read once, when the context is created): RTMI_TEST_FAIL_BATCH=k makes
+  // the k-th batch (from 0) of every render fail after the batches before it were launched; RTMI_TEST_OOM_LANE=w makes the
+  // workspace of internal lane w (and above) report out-of-memory.
+  int test_fail_batch = -1, test_oom_lane = -1;
   unsigned char* scratch = nullptr;  // this device's copy of the static scratch array (rtmi_render_accumulate_noalloc)
   void release_workspace() { for (auto& w : wsm) w.release_queues(); }
 };
@@ -338,24 +346,35 @@ struct KernelClock {
   struct Span { hipEvent_t a, b; bool traverse; };
   std::vector<Span> spans;
   bool on = false;
+  hipError_t error = hipSuccess; // the first failure of an event call; the render reports it
   hipStream_t stream = nullptr;
   double traverse_ms = 0.0;      // of the spans drained so far
   uint32_t traverse_launches = 0;
+  bool open = false;             // begin() recorded a span that end() has to close
+  void note(hipError_t e) { if (e != hipSuccess && error == hipSuccess) error = e; }
   void begin(bool traverse = false) {
     if (traverse) ++traverse_launches;
-    if (!on) return;
-    hipEvent_t a, b;
-    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    (void)hipEventRecord(a, stream);
+    open = false;
+    if (!on || error != hipSuccess) return;
+    hipEvent_t a = nullptr, b = nullptr;
+    note(hipEventCreate(&a));
+    if (error == hipSuccess) note(hipEventCreate(&b));
+    if (error == hipSuccess) note(hipEventRecord(a, stream));
+    if (error != hipSuccess) {     // no half-made span is kept
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+      return;
+    }
     spans.push_back(Span{a, b, traverse});
+    open = true;
   }
-  void end() { if (on) (void)hipEventRecord(spans.back().b, stream); }
+  void end() { if (open) note(hipEventRecord(spans.back().b, stream)); open = false; }
   double drain() {  // waits for the recorded work
     double total = 0.0;
     for (auto& s : spans) {
-      (void)hipEventSynchronize(s.b);
+      note(hipEventSynchronize(s.b));
       float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, s.a, s.b);
+      note(hipEventElapsedTime(&ms, s.a, s.b));
       total += ms;
       if (s.traverse) traverse_ms += ms;
       (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
@@ -465,13 +484,16 @@ extern "C" int rtmi_ctx_create(int device_id, uint64_t max_batch_paths, rtmi_ctx
   if (dev < 0) HIP_TRY(hipGetDevice(&dev));
   if (dev >= n) return fail(RTMI_NO_DEVICE, "device %d requested, %d visible", dev, n);
   HIP_TRY(hipSetDevice(dev));
-  std::unique_ptr<rtmi_ctx> ctx(new rtmi_ctx);
+  // a failure below destroys what was created so far (streams, events), not just the struct
+  std::unique_ptr<rtmi_ctx, void (*)(rtmi_ctx*)> ctx(new rtmi_ctx, rtmi_ctx_destroy);
   ctx->device = dev;
   ctx->max_batch_paths = max_batch_paths ? max_batch_paths : kDefaultBatchPaths;
   ctx->batch_is_default = max_batch_paths == 0;
   if (ctx->max_batch_paths < 256) ctx->max_batch_paths = 256;
   if (ctx->max_batch_paths > (1ull << 30)) ctx->max_batch_paths = 1ull << 30;
   ctx->inline_emit = getenv("RTMI_INLINE_EMIT") != nullptr;
+  if (const char* e = getenv("RTMI_TEST_FAIL_BATCH")) ctx->test_fail_batch = atoi(e);
+  if (const char* e = getenv("RTMI_TEST_OOM_LANE")) ctx->test_oom_lane = atoi(e);
   HIP_TRY(upload_constants(spectrum_tables()));
   if (int rc = static_scratch_address(&ctx->scratch)) return rc;
   if (const char* e = getenv("RTMI_LANES")) ctx->n_lanes = ctx->n_lanes_many = std::min(std::max(atoi(e), 1), kMaxLanes);
@@ -784,7 +806,7 @@ extern "C" int rtmi_intersect_batch(rtmi_scene* s, const rtmi_ray* rays, size_t 
   if (int rc = ensure_workspace(ctx->wsm[0], 1, 0, false, false)) return rc;
   DeviceStats* ds = ctx->wsm[0].ws.stats;
   const bool count = stats != nullptr;
-  if (count) HIP_TRY(hipMemset(ds, 0, sizeof *ds));
+  if (count) HIP_TRY(hipMemset(ds, 0, kPerRenderStatsBytes));
   for (size_t at = 0; at < n; at += chunk) {
     const size_t m = std::min(chunk, n - at);
     HIP_TRY(hipMemcpy(ctx->rays.p, rays + at, m * sizeof(rtmi_ray), hipMemcpyHostToDevice));
@@ -824,7 +846,7 @@ extern "C" int rtmi_trace_batch(rtmi_scene* s, const rtmi_ray* rays, size_t n, u
   if (int rc = ctx->rays.reserve(chunk * sizeof(rtmi_ray))) return rc;
   if (int rc = ctx->spectra_out.reserve(chunk * RT_NBINS * sizeof(float))) return rc;
   DeviceStats* ds = ctx->wsm[0].ws.stats;
-  HIP_TRY(hipMemset(ds, 0, sizeof *ds));
+  HIP_TRY(hipMemset(ds, 0, kPerRenderStatsBytes));
   s->counting = false;
   for (auto& b : s->last_stats) b = nullptr;
   s->last_stats[0] = ds;
@@ -878,12 +900,14 @@ int plan_render(rtmi_scene* s, const rtmi_camera* cam, const rtmi_render_params*
   if (r.T % kPixelBlock != 0 || r.T > 1024) return fail(RTMI_BAD_ARG, "tile_size %u must be a multiple of %u", r.T, kPixelBlock);
   if (p->tile_world && p->tile_rank >= p->tile_world) return fail(RTMI_BAD_ARG, "tile_rank %u >= tile_world %u", p->tile_rank, p->tile_world);
   r.tiles_x = (cam->width + r.T - 1) / r.T; r.tiles_y = (cam->height + r.T - 1) / r.T;
-  const uint32_t all = r.tiles_x * r.tiles_y;
+  const uint64_t all = uint64_t(r.tiles_x) * r.tiles_y;
+  if (all >= (1ull << 32)) return fail(RTMI_UNSUPPORTED, "too many tiles");
   r.first = p->tile_world ? p->tile_rank : 0; r.stride = p->tile_world ? p->tile_world : 1;
-  r.n_tiles = r.first < all ? (all - r.first + r.stride - 1) / r.stride : 0;
+  r.n_tiles = r.first < all ? uint32_t((all - r.first + r.stride - 1) / r.stride) : 0;   // 64-bit: a large stride must not wrap
+  if (p->flags & RTMI_FLAG_EMPTY_SHARE) r.n_tiles = 0;
   r.pixels = 0;
   for (uint32_t j = 0; j < r.n_tiles; ++j) {
-    const uint32_t k = r.first + j * r.stride;
+    const uint32_t k = uint32_t(r.first + uint64_t(j) * r.stride);
     const uint32_t x0 = (k / r.tiles_y) * r.T, y0 = (k % r.tiles_y) * r.T;
     r.pixels += uint64_t(std::min(r.T, cam->width - x0)) * std::min(r.T, cam->height - y0);
   }
@@ -911,12 +935,18 @@ int render_batches(rtmi_scene* s, const Workspace* const* wss, int n_ws, const r
   launch_fill_tiles(wss[0]->tiles, r.n_tiles, r.first, r.stride, stream);
   for (auto& b : s->last_stats) b = nullptr;
   for (int w = 0; w < n_ws; ++w) {
-    HIP_TRY(hipMemsetAsync(wss[w]->stats, 0, sizeof(DeviceStats), stream));
+    HIP_TRY(hipMemsetAsync(wss[w]->stats, 0, kPerRenderStatsBytes, stream));   // the overflow word stays as it is
     s->last_stats[w] = wss[w]->stats;
   }
+  bool forked = false;
   if (n_ws > 1) {
     HIP_TRY(hipEventRecord(ctx->ev_fork, stream));
-    for (int w = 0; w < n_ws; ++w) HIP_TRY(hipStreamWaitEvent(ctx->lane[w], ctx->ev_fork, 0));
+    forked = true;
+    for (int w = 0; w < n_ws; ++w)
+      if (hipError_t e = hipStreamWaitEvent(ctx->lane[w], ctx->ev_fork, 0)) {
+        // lanes that already wait on the fork event have nothing queued behind it: nothing to join
+        return fail(RTMI_HIP_ERROR, "hipStreamWaitEvent on an internal lane: %s", hipGetErrorString(e));
+      }
   }
   KernelClock clock;
   clock.on = (p->flags & RTMI_FLAG_TIME_KERNELS) != 0;
@@ -924,34 +954,52 @@ int render_batches(rtmi_scene* s, const Workspace* const* wss, int n_ws, const r
   uint32_t launches = 0, batches = 0;
   double kernel_ms = 0.0;
   const uint64_t per_tile = uint64_t(r.T) * r.T;
-  for (uint32_t t0 = 0; t0 < r.n_tiles; t0 += tiles_per_batch) {
-    const uint32_t nt = std::min(tiles_per_batch, r.n_tiles - t0);
-    for (uint32_t s0 = r.s_begin; s0 < r.s_end; s0 += samples_per_batch) {
-      const int w = n_ws > 1 ? int(batches % uint32_t(n_ws)) : 0;
-      const Workspace& ws = *wss[w];
-      hipStream_t lane = n_ws > 1 ? ctx->lane[w] : stream;
-      BatchDesc b{};
-      b.cam = to_dev_camera(*cam);
-      b.tile_list = ws.tiles + t0; b.n_tiles = nt; b.tile_size = r.T; b.tiles_y = r.tiles_y;
-      b.n_local_pixels = uint32_t(nt * per_tile);
-      b.by_local_pixels = make_fast_div(b.n_local_pixels); b.by_tile_pixels = make_fast_div(uint32_t(per_tile));
-      b.by_tiles_y = make_fast_div(r.tiles_y); b.by_blocks_per_row = make_fast_div(r.T / kPixelBlock);
-      b.sample0 = s0; b.n_samples = std::min(samples_per_batch, r.s_end - s0);
-      b.integrator = p->integrator; b.max_depth = p->max_depth; b.seed = p->seed;
-      const size_t n_paths = size_t(b.n_local_pixels) * b.n_samples;
-      // the workspace is free again once the batch that last used it has been added to the sums
-      if (n_ws > 1 && batches >= uint32_t(n_ws)) HIP_TRY(hipStreamWaitEvent(lane, ctx->ev_resolved[w], 0));
-      if (int rc = run_batch(s, ws, b, n_paths, nullptr, lane, clock, launches)) return rc;
-      if (n_ws > 1) {
-        HIP_TRY(hipEventRecord(ctx->ev_done[w], lane));
-        HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done[w], 0));
-      }
-      launch_resolve(b, TraceOutputs{ws.contrib, ws.contrib + n_paths, ws.contrib + 2 * n_paths, nullptr, EmitQueue{}, nullptr, 0}, dev_xyz_sum, stream);
-      HIP_TRY(hipGetLastError());
-      if (n_ws > 1) HIP_TRY(hipEventRecord(ctx->ev_resolved[w], stream));
-      if (clock.on) kernel_ms += clock.drain();
-      ++batches;
+  // One batch. A failure leaves through `rc`; the caller's stream is then joined with the lanes below, so that work the
+  // caller queues on `stream` after a failed render cannot overlap what the lanes still have in flight.
+  auto one_batch = [&](uint32_t t0, uint32_t nt, uint32_t s0) -> int {
+    const int w = n_ws > 1 ? int(batches % uint32_t(n_ws)) : 0;
+    const Workspace& ws = *wss[w];
+    hipStream_t lane = n_ws > 1 ? ctx->lane[w] : stream;
+    BatchDesc b{};
+    b.cam = to_dev_camera(*cam);
+    b.tile_list = ws.tiles + t0; b.n_tiles = nt; b.tile_size = r.T; b.tiles_y = r.tiles_y;
+    b.n_local_pixels = uint32_t(nt * per_tile);
+    b.by_local_pixels = make_fast_div(b.n_local_pixels); b.by_tile_pixels = make_fast_div(uint32_t(per_tile));
+    b.by_tiles_y = make_fast_div(r.tiles_y); b.by_blocks_per_row = make_fast_div(r.T / kPixelBlock);
+    b.sample0 = s0; b.n_samples = std::min(samples_per_batch, r.s_end - s0);
+    b.integrator = p->integrator; b.max_depth = p->max_depth; b.seed = p->seed;
+    const size_t n_paths = size_t(b.n_local_pixels) * b.n_samples;
+    if (ctx->test_fail_batch >= 0 && batches == uint32_t(ctx->test_fail_batch))
+      return fail(RTMI_INTERNAL, "injected failure at batch %u (RTMI_TEST_FAIL_BATCH)", batches);
+    // the workspace is free again once the batch that last used it has been added to the sums
+    if (n_ws > 1 && batches >= uint32_t(n_ws)) HIP_TRY(hipStreamWaitEvent(lane, ctx->ev_resolved[w], 0));
+    if (int rc = run_batch(s, ws, b, n_paths, nullptr, lane, clock, launches)) return rc;
+    if (n_ws > 1) {
+      HIP_TRY(hipEventRecord(ctx->ev_done[w], lane));
+      HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done[w], 0));
     }
+    launch_resolve(b, TraceOutputs{ws.contrib, ws.contrib + n_paths, ws.contrib + 2 * n_paths, nullptr, EmitQueue{}, nullptr, 0}, dev_xyz_sum, stream);
+    HIP_TRY(hipGetLastError());
+    if (n_ws > 1) HIP_TRY(hipEventRecord(ctx->ev_resolved[w], stream));
+    if (clock.on) kernel_ms += clock.drain();
+    if (clock.error != hipSuccess) return fail(RTMI_HIP_ERROR, "HIP event of RTMI_FLAG_TIME_KERNELS: %s", hipGetErrorString(clock.error));
+    ++batches;
+    return RTMI_OK;
+  };
+  int rc = RTMI_OK;
+  for (uint32_t t0 = 0; t0 < r.n_tiles && rc == RTMI_OK; t0 += tiles_per_batch) {
+    const uint32_t nt = std::min(tiles_per_batch, r.n_tiles - t0);
+    for (uint32_t s0 = r.s_begin; s0 < r.s_end && rc == RTMI_OK; s0 += samples_per_batch) rc = one_batch(t0, nt, s0);
+  }
+  if (rc != RTMI_OK) {
+    const std::string message = g_error;     // the joins below must not replace the failure's own message
+    (void)clock.drain();
+    if (forked)
+      for (int w = 0; w < n_ws; ++w)
+        if (hipEventRecord(ctx->ev_done[w], ctx->lane[w]) == hipSuccess) (void)hipStreamWaitEvent(stream, ctx->ev_done[w], 0);
+    (void)hipGetLastError();
+    g_error = message;
+    return rc;
   }
   s->pending.launches = launches; s->pending.batches = batches; s->pending.ms_kernels = kernel_ms;
   s->pending.ms_traverse = clock.traverse_ms; s->pending.traverse_launches = clock.traverse_launches;
@@ -994,13 +1042,24 @@ extern "C" int rtmi_render_accumulate(rtmi_scene* s, const rtmi_camera* cam, con
     const uint64_t n_batches = ((r.n_tiles + tiles_per_batch - 1) / tiles_per_batch) * uint64_t((n_samples + samples_per_batch - 1) / samples_per_batch);
     n_ws = int(std::min<uint64_t>(uint64_t(lanes), n_batches));
     int rc = RTMI_OK;
-    for (int w = 0; w < n_ws && rc == RTMI_OK; ++w) rc = ensure_workspace(ctx->wsm[w], batch_paths, samples_per_batch, r.deep, r.want_queues);
+    for (int w = 0; w < n_ws && rc == RTMI_OK; ++w) {
+      if (ctx->test_oom_lane >= 0 && w >= ctx->test_oom_lane) rc = fail(RTMI_OOM, "injected out-of-memory for lane %d (RTMI_TEST_OOM_LANE)", w);
+      else rc = ensure_workspace(ctx->wsm[w], batch_paths, samples_per_batch, r.deep, r.want_queues);
+    }
     if (rc == RTMI_OK) break;
-    // The default batch is sized for an otherwise empty 288 GB device. If the workspace does not fit, halve the
-    // batch (the image does not depend on it) rather than fail; a caller-chosen cap is never second-guessed.
-    if (rc != RTMI_OOM || !ctx->batch_is_default || ctx->max_batch_paths <= (1ull << 20)) return rc;
+    if (rc != RTMI_OOM) return rc;
     (void)hipGetLastError();
     ctx->release_workspace();
+    // Every lane holds a workspace of its own, so a context's memory is (lanes in use) x (one batch). Short of memory, the
+    // overlap goes first: fewer lanes, down to one, with the batch the caller asked for ...
+    if (lanes > 1) {
+      ctx->n_lanes = std::min(ctx->n_lanes, lanes - 1);
+      ctx->n_lanes_many = std::min(ctx->n_lanes_many, lanes - 1);
+      continue;
+    }
+    // ... and only the library's own default batch (sized for an otherwise empty 288 GB device) is then halved: the image
+    // does not depend on it. A cap the caller chose is never second-guessed.
+    if (!ctx->batch_is_default || ctx->max_batch_paths <= (1ull << 20)) return rc;
     ctx->max_batch_paths >>= 1;
   }
   if (int rc = ctx->tiles.reserve(size_t(r.n_tiles) * sizeof(uint32_t))) return rc;
@@ -1075,9 +1134,13 @@ extern "C" int rtmi_render_collect_stats(rtmi_scene* s, void* stream_, rtmi_stat
     if (!block) continue;
     DeviceStats h;
     HIP_TRY(hipMemcpy(&h, block, sizeof h, hipMemcpyDeviceToHost));
-    if (h.overflow)
-      return fail(RTMI_INTERNAL, "a path-queue region overflowed and paths were dropped: the image of this render is incomplete "
+    if (h.overflow) {
+      // reported once: the word is sticky on the device (a render does not clear it), so it is cleared here
+      (void)hipMemset(reinterpret_cast<char*>(block) + offsetof(DeviceStats, overflow), 0, sizeof(uint32_t));
+      return fail(RTMI_INTERNAL, "a path-queue region overflowed and paths were dropped: the image of this render, or of a render "
+                                 "before it on this context whose statistics were not collected, is incomplete "
                                  "(internal sizing error; please report the scene and the batch size)");
+    }
     stats->segments += h.bounce_segments;
     stats->nodes_visited += h.trav.nodes; stats->prims_tested += h.trav.prims; stats->mesh_rays += h.mesh_rays;
     trav.nodes += h.trav.nodes; trav.prims += h.trav.prims; trav.node_slots += h.trav.node_slots; trav.prim_slots += h.trav.prim_slots;

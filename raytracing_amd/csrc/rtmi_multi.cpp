@@ -123,6 +123,10 @@ struct rtmi_multi {
   size_t staging_floats = 0;
   uint8_t* rgb8 = nullptr;        // first device
   size_t rgb8_bytes = 0;
+  // the progressive render in flight (rtmi_multi_render_pass): which pass comes next, of how many, and what it renders
+  uint32_t next_pass = 0, n_passes = 0, pass_partition = 0;
+  rtmi_camera pass_cam{};
+  rtmi_render_params pass_params{};
 };
 
 #define HIP_TRY(expr)                                                                                       \
@@ -203,6 +207,7 @@ int ensure_rank_buffers(rtmi_multi* m, size_t n_pix) {
     if (r.sums_floats < n_pix * 3) {
       if (r.sums) { (void)hipFree(r.sums); r.sums = nullptr; r.sums_floats = 0; }
       HIP_TRY(hipMalloc(reinterpret_cast<void**>(&r.sums), n_pix * 3 * sizeof(float)));
+      HIP_TRY(hipMemset(r.sums, 0, n_pix * 3 * sizeof(float)));   // never handed out uninitialised
       r.sums_floats = n_pix * 3;
     }
   }
@@ -257,7 +262,7 @@ int render_samples(rtmi_multi* m, const rtmi_camera* cam, const rtmi_render_para
       const uint32_t end = begin + base + (i < extra ? 1u : 0u);
       p.sample_begin = begin; p.sample_end = end;
       // more ranks than samples: this rank gets an empty tile share (it still clears its buffer for the merge)
-      if (end == begin) { p.sample_begin = p.sample_end = 0; p.tile_world = 0xFFFFFFFFu; p.tile_rank = 0xFFFFFFFEu; }
+      if (end == begin) { p.sample_begin = p.sample_end = 0; p.flags |= RTMI_FLAG_EMPTY_SHARE; }
     } else {
       p.tile_rank = uint32_t(i); p.tile_world = uint32_t(n);
       p.sample_begin = s_begin; p.sample_end = s_end;
@@ -276,9 +281,10 @@ int render_samples(rtmi_multi* m, const rtmi_camera* cam, const rtmi_render_para
     for (size_t i = 0; i < n && rc == 0 && hip_rc == hipSuccess; ++i) {
       Rank& r = m->ranks[i];
       hip_rc = hipSetDevice(r.device);
-      // the receive buffer only matters on the root; the ranks' own sums stay as they are for the next pass
+      // ncclReduce only uses the receive buffer on the root; the other ranks pass none, so that nothing can touch their own
+      // sums, which the next pass of a progressive render adds to
       if (hip_rc == hipSuccess)
-        rc = m->rccl->Reduce(r.sums, i == 0 ? m->total : r.sums, n_pix * 3, Rccl::kFloat32, Rccl::kSum, 0, r.comm, r.stream);
+        rc = m->rccl->Reduce(r.sums, i == 0 ? m->total : nullptr, n_pix * 3, Rccl::kFloat32, Rccl::kSum, 0, r.comm, r.stream);
     }
     const int rc_end = m->rccl->GroupEnd();   // the group is closed on every path, also after a failed call inside it
     if (rc == 0) rc = rc_end;
@@ -344,6 +350,7 @@ int check_multi_args(const rtmi_multi* m, const rtmi_camera* cam, const rtmi_ren
 extern "C" int rtmi_multi_render(rtmi_multi* m, const rtmi_camera* cam, const rtmi_render_params* params, uint32_t partition,
                                  uint8_t* host_rgb8, float* host_xyz, rtmi_stats* stats, rtmi_stats* per_rank_stats) {
   if (int rc = check_multi_args(m, cam, params, partition, host_rgb8, host_xyz)) return rc;
+  m->n_passes = m->next_pass = 0;   // a whole render clears the ranks' sums: a progressive render in flight is over
   return render_samples(m, cam, params, partition, 0, params->spp, true, params->spp, host_rgb8, host_xyz, stats, per_rank_stats);
 }
 
@@ -352,8 +359,21 @@ extern "C" int rtmi_multi_render_pass(rtmi_multi* m, const rtmi_camera* cam, con
   if (int rc = check_multi_args(m, cam, params, partition, host_rgb8, host_xyz)) return rc;
   if (n_passes == 0 || pass >= n_passes || n_passes > params->spp)
     return fail(RTMI_BAD_ARG, "pass %u of %u over %u samples", pass, n_passes, params->spp);
+  // The ranks' sums carry over from pass to pass: pass 0 starts a render (and clears them), every later pass must be the
+  // next one of that same render -- same pass count, partition, camera and parameters -- or it would add to sums that
+  // belong to another image.
+  if (pass == 0) {
+    m->n_passes = n_passes; m->pass_partition = partition; m->pass_cam = *cam; m->pass_params = *params;
+  } else if (m->n_passes != n_passes || m->next_pass != pass || m->pass_partition != partition ||
+             std::memcmp(&m->pass_cam, cam, sizeof *cam) != 0 || std::memcmp(&m->pass_params, params, sizeof *params) != 0) {
+    return fail(RTMI_BAD_ARG, "pass %u of %u does not continue the progressive render in flight (next pass %u of %u): passes run "
+                              "in order from 0 with the same camera, parameters and partition", pass, n_passes, m->next_pass, m->n_passes);
+  }
   // balanced contiguous sample ranges, like the ranks' own
   const uint32_t base = params->spp / n_passes, extra = params->spp % n_passes;
   const uint32_t begin = pass * base + std::min(pass, extra), end = begin + base + (pass < extra ? 1u : 0u);
-  return render_samples(m, cam, params, partition, begin, end, pass == 0, end, host_rgb8, host_xyz, stats, nullptr);
+  const int rc = render_samples(m, cam, params, partition, begin, end, pass == 0, end, host_rgb8, host_xyz, stats, nullptr);
+  if (rc == RTMI_OK) m->next_pass = pass + 1;
+  else m->n_passes = m->next_pass = 0;      // the sums are in an unknown state: the render has to start again at pass 0
+  return rc;
 }

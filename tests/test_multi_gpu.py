@@ -100,3 +100,38 @@ def test_progressive_passes_add_up_to_the_single_render():
     with pytest.raises(L.RtmiError):
         m.render_pass(cam, p, L.PARTITION_TILES, 3, 3)
     m.close()
+
+
+def test_passes_out_of_order_are_refused():
+    """The ranks' sums carry over between passes, so a pass that does not continue the render in flight -- a fresh handle
+    asked for pass 1, a pass skipped or repeated, another camera, sample count or partition half way -- must be refused
+    (RTMI_BAD_ARG) instead of adding to sums that belong to another image; and a refused pass must not disturb the
+    render in flight."""
+    from raytracing_amd import api, _lib as L
+    kw = dict(width=96, height=54)
+    b, _ = scenes.scene3(from_rgb=None, **kw)
+    p = api.render_params(O.INT_RANDOM_WALK, 6, 6, seed=4)
+    cam, (full8, full_xyz, _) = _single(scenes.scene3, p, **kw)
+    m = api.MultiScene([0, 0], *b.arrays(), max_batch_paths=1 << 22)
+
+    def refused(*args):
+        with pytest.raises(L.RtmiError) as e:
+            m.render_pass(*args)
+        assert e.value.code == L.BAD_ARG
+
+    refused(cam, p, L.PARTITION_TILES, 1, 3)                      # nothing in flight
+    m.render_pass(cam, p, L.PARTITION_TILES, 0, 3)
+    refused(cam, p, L.PARTITION_TILES, 2, 3)                      # skips pass 1
+    refused(cam, p, L.PARTITION_TILES, 1, 2)                      # another pass count
+    refused(cam, p, L.PARTITION_SAMPLES, 1, 3)                    # another partition
+    refused(cam, api.render_params(O.INT_RANDOM_WALK, 6, 9, seed=4), L.PARTITION_TILES, 1, 3)    # another sample count
+    other = api.camera_new((-4.5, 0.0, 2.0), 0.1, 120.0, (0.0, 0.5, 0.0), 64, 36)
+    refused(other, p, L.PARTITION_TILES, 1, 3)                    # another resolution
+    m.render_pass(cam, p, L.PARTITION_TILES, 1, 3)
+    refused(cam, p, L.PARTITION_TILES, 1, 3)                      # repeats pass 1
+    img, xyz, _ = m.render_pass(cam, p, L.PARTITION_TILES, 2, 3)
+    assert (img == full8).all() and (xyz.view(np.uint32) == full_xyz.view(np.uint32)).all()
+    # a whole render ends the progressive one
+    m.render(cam, p, L.PARTITION_TILES)
+    refused(cam, p, L.PARTITION_TILES, 1, 3)
+    m.close()
