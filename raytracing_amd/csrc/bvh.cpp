@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -13,10 +14,12 @@ namespace {
 
 constexpr int kBins = 16;
 constexpr uint32_t kForceMedianDepth = 40;  // past this depth splits are balanced, so depth stays bounded
-// Relative cost of a box-test step and a triangle test in the surface-area heuristic. Measured on the GPU (Suzanne,
-// first-index rule, leaves of at most 4): 0.7 gives the shortest traversal launches (1.05 ms against 1.11 at 1.5 and
-// 1.12 at 0.4): a step through the wave-level scheduler costs more than one binary64 triangle test.
-constexpr double kTraversalCost = 1.0, kTriangleCost = 0.7;
+// Relative cost of a box-test step and a triangle test in the surface-area heuristic, measured on the GPU (Suzanne,
+// first-index rule, leaves of at most 4, 1920x1080x64 spp): with the box test at 48 vector instructions for both children
+// (binary16 planes) and the binary64 triangle test at about 100, the step takes 16.99 ms at 0.5, 16.5 at 0.7, 16.35 at 0.9,
+// 16.25 at 1.1, 16.20 at 1.4 and 16.30 at 1.8; the nearest rule and the million-triangle mesh move by 1 % the same way.
+constexpr double kTraversalCost = 1.0;
+static double kTriangleCost = 1.2;   // RTMI_SAH_TRIANGLE_COST overrides it (read when a tree is built; for measurements)
 
 struct Box {
   double lo[3], hi[3];
@@ -148,6 +151,7 @@ struct Builder {
 }  // namespace
 
 BvhBuild build_bvh(const double* tri_vertices, uint32_t n, uint32_t leaf_size) {
+  if (const char* e = getenv("RTMI_SAH_TRIANGLE_COST")) { const double c = atof(e); if (c > 0.0) kTriangleCost = c; }
   Builder bld;
   bld.verts = tri_vertices;
   bld.leaf_size = std::max(1u, std::min(leaf_size, uint32_t(RT_LEAF_MAX_TRIS)));
