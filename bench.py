@@ -287,6 +287,45 @@ def dry_run(args, world, rank):
         dist.destroy_process_group()
 
 
+def in_process_devices(args, w):
+    """One process, several GPUs behind the C ABI: rtmi_multi_render partitions the render over the devices (sample ranges or
+    interleaved tiles), runs one host thread per device and merges the sums with one ncclReduce inside the library -- the
+    path the Rust shim calls. Strong scaling (the workload's spp are split). The call returns the image on the host, so
+    unlike the rank path the time includes the copy of the 8-bit image back (W * H * 3 bytes)."""
+    import time as _t
+    from raytracing_amd import api, scenes, _lib as L
+    n = args.devices
+    ids = [0] * n if args.share_gpu else list(range(n))
+    hit_rule = L.HIT_FIRST_INDEX if args.rule == "first_index" else L.HIT_NEAREST
+    kw = {k: v for k, v in w.items() if k in ("width", "height", "specular_mesh")}
+    builder, cam_args = getattr(scenes, w["recipe"])(from_rgb=None, **kw)
+    t_build = _t.perf_counter()
+    multi = api.MultiScene(ids, *builder.arrays(), hit_rule=hit_rule, max_batch_paths=args.batch_paths)
+    build_s = _t.perf_counter() - t_build
+    cam = api.camera_new(*cam_args)
+    p = api.render_params(L.INT_RANDOM_WALK, w["depth"], w["spp"], seed=0)
+    part = L.PARTITION_SAMPLES if args.partition == "samples" else L.PARTITION_TILES
+    for _ in range(args.warmup):
+        multi.render(cam, p, part, want_xyz=False)
+    t0 = _t.perf_counter()
+    segments = 0
+    for _ in range(args.steps):
+        _, _, st, per = multi.render(cam, p, part, want_xyz=False)
+        segments += st["segments"]
+    elapsed = _t.perf_counter() - t0
+    info = multi.info()
+    print(json.dumps({
+        "metric": "Mpath-segments/sec (whole node)", "value": segments / elapsed / 1e6, "unit": "Mseg/s", "n_gpus": n,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": args.workload, "width": cam.width, "height": cam.height, "spp_job": w["spp"], "max_depth": w["depth"],
+                   "integrator": "RandomWalk", "hit_rule": args.rule, "partition": args.partition, "devices": ids,
+                   "scene_build_s": build_s, "image_copied_to_host": True},
+        "world_size": 1, "backend": "rtmi_multi (ncclReduce inside the library)" if info["uses_rccl"] else "rtmi_multi (copies and adds)",
+        "per_rank_segments": [s["segments"] for s in per], "roofline": None, "cpu_baseline": None}), flush=True)
+    multi.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -325,6 +364,8 @@ def main():
         return dry_run(args, world, rank)
 
     w = WORKLOADS[args.workload]
+    if args.devices > 0:
+        return in_process_devices(args, w)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # first, while the GPU is idle: it is the long leg of the run

@@ -28,6 +28,7 @@ def test_self_launch_two_ranks():
     assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["merge_ok"]
     shares = [tuple(p["share"]["sample_range"]) for p in sorted(out["per_rank"], key=lambda p: p["rank"])]
     assert shares == [(0, 64), (64, 128)]          # weak scaling in samples: every rank its own 64 of a 128-spp job
+    assert out["scaling"] == "weak" and out["spp_job"] == 128
 
 
 def test_under_torch_distributed_run_with_tiles():
@@ -38,6 +39,18 @@ def test_under_torch_distributed_run_with_tiles():
     out = _line(r.stdout)
     assert out["world_size"] == 2 and out["merge_ok"]
     assert [p["share"] for p in sorted(out["per_rank"], key=lambda p: p["rank"])] == [{"tile_rank": 0, "tile_world": 2}, {"tile_rank": 1, "tile_world": 2}]
+
+
+def test_strong_scaling_splits_the_samples():
+    """--scaling strong under the sample partition: the job keeps the workload's 64 spp and every rank renders its share of
+    them (the 256-spp-over-8-GPUs form of the million-triangle configuration), where the default gives every rank 64."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry-run", "--scaling", "strong", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=_env())
+    assert r.returncode == 0, r.stderr
+    out = _line(r.stdout)
+    assert out["world_size"] == 2 and out["merge_ok"] and out["scaling"] == "strong" and out["spp_job"] == 64
+    shares = [tuple(p["share"]["sample_range"]) for p in sorted(out["per_rank"], key=lambda p: p["rank"])]
+    assert shares == [(0, 32), (32, 64)]
 
 
 def test_world_size_mismatch_is_an_error():

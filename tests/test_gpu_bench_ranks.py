@@ -38,3 +38,20 @@ def test_two_ranks_on_one_gpu_by_samples_and_by_tiles():
     assert tiles["scaling"] == "strong" and tiles["config"]["spp_job"] == one["config"]["spp_job"]
     total_t = tiles["value"] * 1e6 * tiles["ms_per_step"] * 1e-3
     assert round(total_t) == seg1          # the same paths, dealt out by tiles: the same segments exactly
+
+
+def test_strong_scaling_by_samples_and_the_in_process_devices_leg():
+    """--scaling strong: two ranks split the workload's samples, so the job's segments are one rank's; --devices N runs
+    the same split inside one process through rtmi_multi_render (here two shares on device 0: copies and adds)."""
+    one = _run([])
+    seg1 = one["config"]["segments_per_step_per_gpu"]
+    strong = _run(["--gpus", "2", "--share-gpu", "--scaling", "strong"])
+    assert strong["scaling"] == "strong" and strong["config"]["spp_job"] == one["config"]["spp_job"]
+    assert strong["config"]["spp_per_gpu"] == one["config"]["spp_job"] / 2
+    assert round(strong["value"] * 1e6 * strong["ms_per_step"] * 1e-3) == seg1
+    assert one["mesh_rays_per_step"] > 0 and abs(strong["mesh_rays_per_step"] - one["mesh_rays_per_step"]) < 1
+    multi = _run(["--devices", "2", "--share-gpu"])
+    assert multi["n_gpus"] == 2 and multi["scaling"] == "strong" and multi["backend"].startswith("rtmi_multi")
+    assert round(multi["value"] * 1e6 * multi["ms_per_step"] * 1e-3) == seg1 and sum(multi["per_rank_segments"]) >= seg1
+    single = _run(["--devices", "1"])
+    assert round(single["value"] * 1e6 * single["ms_per_step"] * 1e-3) == seg1
