@@ -346,7 +346,7 @@ template <int FMT> __device__ __forceinline__ float q_hi16(uint32_t w) {
 // Both children of the node at `np` against the ray: slab tests on the quantised planes (a zero direction component
 // gives +-inf or NaN; fminf/fmaxf drop a NaN operand, which only makes the test more permissive), the final comparison
 // allowing for the rounding of the plane distances; then the references and minimum indices in the format's form.
-template <int FMT>
+template <int FMT, bool BOUNDED = true>
 __device__ __forceinline__ Children test_children(const uint4* __restrict__ np, const QuantRay& r, float tmax) {
   const uint4 w0 = np[0], w1 = np[1];
   Children c;
@@ -355,7 +355,9 @@ __device__ __forceinline__ Children test_children(const uint4* __restrict__ np, 
     const float ay = __builtin_fmaf(q_hi16<FMT>(w0.x), r.sy, r.ly), by = __builtin_fmaf(q_lo16<FMT>(w0.z), r.sy, r.hy);
     const float az = __builtin_fmaf(q_lo16<FMT>(w0.y), r.sz, r.lz), bz = __builtin_fmaf(q_hi16<FMT>(w0.z), r.sz, r.hz);
     const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    // BOUNDED = false: the caller has no upper bound on t (first-index rule), and the min with +inf is left out
+    const float tf = BOUNDED ? fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax))
+                             : fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     c.tn0 = tn; c.h0 = tn <= tf * 1.000002f;
   }
   {
@@ -363,7 +365,8 @@ __device__ __forceinline__ Children test_children(const uint4* __restrict__ np, 
     const float ay = __builtin_fmaf(q_hi16<FMT>(w0.w), r.sy, r.ly), by = __builtin_fmaf(q_lo16<FMT>(w1.y), r.sy, r.hy);
     const float az = __builtin_fmaf(q_lo16<FMT>(w1.x), r.sz, r.lz), bz = __builtin_fmaf(q_hi16<FMT>(w1.y), r.sz, r.hz);
     const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    const float tf = BOUNDED ? fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax))
+                             : fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     c.tn1 = tn; c.h1 = tn <= tf * 1.000002f;
   }
   if (FMT == RT_NODES_SMALL) {
@@ -1581,7 +1584,7 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
           if (COUNT) count_slot(w_nodes);
           if (COUNT) ++n_nodes;
           const float tmax = RULE == RT_HIT_NEAREST ? __double2float_ru(mh.t) * 1.000002f : INFINITY;
-          const Children c = test_children<FMT>(node_words + (size_t(root) + cur) * F::kWords4, qr, tmax);
+          const Children c = test_children<FMT, RULE == RT_HIT_NEAREST>(node_words + (size_t(root) + cur) * F::kWords4, qr, tmax);
           const uint32_t ref0 = c.ref0, ref1 = c.ref1, min0 = c.min0, min1 = c.min1;
           const float tn0 = c.tn0, tn1 = c.tn1;
           bool h0 = c.h0, h1 = c.h1;
