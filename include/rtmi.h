@@ -163,7 +163,7 @@ typedef struct rtmi_scene rtmi_scene;
 
 /* Binds a context to GPU `device_id` (-1 = the current HIP device). Replaces nothing in the
  * reference: the reference has no device. max_batch_paths caps the path slots one render batch uses;
- * 0 = default, 2^27 slots. A batch needs about 210 bytes of workspace per slot (two path queues, the
+ * 0 = default, 2^28 slots. A batch needs about 210 bytes of workspace per slot (two path queues, the
  * traversal list, the emit queue, the per-slot contributions), allocated only up to what a render
  * actually needs. A render overlaps its batches on up to three internal lanes, each with a workspace
  * of its own, so a context holds up to 3 x (one batch) of device memory; when that does not fit, the

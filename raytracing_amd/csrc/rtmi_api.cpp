@@ -172,10 +172,12 @@ struct rtmi_scene {
 
 namespace {
 
-// Default number of path slots per batch of launches: 128 Mi, about 31 GB of workspace out of 288 GB. A launch over a
-// deep queue level is bound by the longest traversals in it, not by how many paths it holds, so the fewer and larger the
-// batches, the fewer of those tails a render pays for (1080p x 64 spp fits one batch).
-constexpr uint64_t kDefaultBatchPaths = 1ull << 27;
+// Default number of path slots per batch of launches: 256 Mi, about 56 GB of workspace per lane (three lanes when a
+// render has several batches: 170 GB of the 288 GB). A launch over a deep queue level is bound by the longest traversals
+// in it, not by how many paths it holds, so the fewer and larger the batches, the fewer of those tails a render pays for:
+// the 2.1 G paths of the million-triangle 4K render take 180 ms in 16 batches of 2^27, 167 ms in 8 of 2^28 and 164 ms in
+// 4 of 2^29 on two lanes (1080p x 64 spp fits one batch either way). Short of memory the lanes go first, then this halves.
+constexpr uint64_t kDefaultBatchPaths = 1ull << 28;
 
 int bind(const rtmi_ctx* ctx) {
   HIP_TRY(hipSetDevice(ctx->device));

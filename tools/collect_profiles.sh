@@ -16,6 +16,7 @@ while read -r suffix name key; do
 done <<LIST
 - suzanne suzanne_1080p_64spp/first_index
 _mesh1m mesh1m mesh1m_4k_256spp/nearest
+_mesh1m_first mesh1m_first_index mesh1m_4k_16spp/first_index
 _near suzanne_nearest suzanne_1080p_64spp/nearest
 _scene3 scene3 scene3_720p_100spp/first_index
 _scene3ext scene3_extended scene3_extended_4k_16spp/first_index
