@@ -19,8 +19,7 @@ _mesh1m mesh1m mesh1m_4k_256spp/nearest
 _mesh1m_first mesh1m_first_index mesh1m_4k_16spp/first_index
 _near suzanne_nearest suzanne_1080p_64spp/nearest
 _scene3 scene3 scene3_720p_100spp/first_index
-_scene3ext scene3_extended scene3_extended_4k_16spp/first_index
+_scene3ext scene3_extended_16spp scene3_extended_4k_16spp/first_index
+_scene3ext1024 scene3_extended scene3_extended_4k_1024spp/first_index
 LIST
-# the deep-bounce workload at its full sample count runs batches of the size of the 16-spp run's single batch
-[ -d gpurun_out/prof_${tag}_scene3ext ] && python3 tools/pmc_summary.py gpurun_out/prof_${tag}_scene3ext scene3_extended_4k_1024spp/first_index > /dev/null
 ls profiles/${round}_*

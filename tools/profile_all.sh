@@ -8,3 +8,4 @@ bash tools/profile_bench.sh prof_${tag}_mesh1m --workload mesh1m_4k_256spp --rul
 bash tools/profile_bench.sh prof_${tag}_mesh1m_first --workload mesh1m_4k_16spp --rule first_index
 bash tools/profile_bench.sh prof_${tag}_scene3 --workload scene3_720p_100spp
 bash tools/profile_bench.sh prof_${tag}_scene3ext --workload scene3_extended_4k_16spp
+bash tools/profile_bench.sh prof_${tag}_scene3ext1024 --workload scene3_extended_4k_1024spp
