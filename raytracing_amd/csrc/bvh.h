@@ -31,6 +31,17 @@ struct QuantizedNodes {
   std::vector<RtWord4> words;        // 2 (SMALL, NEAREST) or 3 (WIDE) per node, in node order
 };
 QuantizedNodes quantize_nodes(const BvhBuild& build, int format);
-inline uint32_t node_words4(int format) { return format == RT_NODES_WIDE ? 3u : 2u; }
+inline uint32_t node_words4(int format) { return format == RT_NODES_QUAD ? 4u : (format == RT_NODES_WIDE ? 3u : 2u); }
+
+// The same tree with four children per node (RT_NODES_QUAD): starting at the root, a node's inner child with the largest
+// box is replaced by that child's own two children until the node has four children or only leaves; the children that
+// are still inner nodes become four-wide nodes the same way. Leaves and their triangle order are the binary tree's.
+// n_nodes = four-wide nodes made; max_depth = deepest chain of them; max_stack = the most references a walk can have
+// stacked at once (the other children of every node along one path, plus one), which is what sizes the kernels' stacks.
+struct QuadNodes : QuantizedNodes { uint32_t n_nodes = 0, max_depth = 0, max_stack = 0; };
+QuadNodes quantize_nodes_quad(const BvhBuild& build);
+// Every reference of the four-wide nodes is in range, every node but the root has exactly one parent before it, and the
+// leaves cover every triangle exactly once: what the kernels rely on when they follow these references.
+bool verify_quad_nodes(const BvhBuild& build, const QuadNodes& q);
 
 }  // namespace rtmi

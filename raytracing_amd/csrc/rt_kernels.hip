@@ -294,7 +294,7 @@ __device__ __forceinline__ bool model_gate_certain(const DevObject& ob, const Bo
 // How a node format (rt_types.h: RT_NODES_*) names children. `kLeaf` marks a leaf reference, `kNone` an empty slot
 // and, as the current node of a lane, "traversal finished" (it carries the leaf bit, so it also ends a node loop).
 template <int FMT> struct NodeFmt {
-  static constexpr uint32_t kWords4 = FMT == RT_NODES_WIDE ? 3u : 2u;
+  static constexpr uint32_t kWords4 = FMT == RT_NODES_QUAD ? 4u : (FMT == RT_NODES_WIDE ? 3u : 2u);
   static constexpr uint32_t kLeaf = FMT == RT_NODES_SMALL ? RT_SMALL_LEAF_FLAG : RT_LEAF_FLAG;
   static constexpr uint32_t kNone = FMT == RT_NODES_SMALL ? RT_SMALL_REF_NONE : RT_REF_NONE;
   // what a traversal-stack entry is: the 16-bit references of the small format halve the stacks' LDS, which is what
@@ -314,18 +314,19 @@ template <int FMT> struct NodeFmt {
 struct QuantRay { float sx, sy, sz, lx, ly, lz, hx, hy, hz; };
 
 __device__ __forceinline__ QuantRay make_quant_ray(const BoxRay& r, const DevObject& ob) {
+  // A direction component that is zero, or so small that its reciprocal overflows, would make these products infinite, and
+  // a plane distance "finite * inf + (-+inf)" is an infinity or a NaN depending on the plane's sign: boxes the ray runs
+  // inside of would be rejected. The reciprocals are therefore held to +-2^40. A ray that shallow moves less than
+  // 2^-40 of the distance it travels along that axis -- far less than delta over any distance that matters -- so its slab
+  // test is a containment test of the origin, which is what these finite products then compute: planes on either side of
+  // the origin land at -+(their distance) * 2^40, planes on one side both far out on that side.
+  const float ix = fminf(fmaxf(r.ix, -0x1.0p40f), 0x1.0p40f), iy = fminf(fmaxf(r.iy, -0x1.0p40f), 0x1.0p40f),
+              iz = fminf(fmaxf(r.iz, -0x1.0p40f), 0x1.0p40f);
   QuantRay q;
-  q.sx = ob.grid_step[0] * r.ix; q.sy = ob.grid_step[1] * r.iy; q.sz = ob.grid_step[2] * r.iz;
-  q.lx = (ob.grid_lo[0] - (r.ox + r.delta)) * r.ix; q.hx = (ob.grid_lo[0] - (r.ox - r.delta)) * r.ix;
-  q.ly = (ob.grid_lo[1] - (r.oy + r.delta)) * r.iy; q.hy = (ob.grid_lo[1] - (r.oy - r.delta)) * r.iy;
-  q.lz = (ob.grid_lo[2] - (r.oz + r.delta)) * r.iz; q.hz = (ob.grid_lo[2] - (r.oz - r.delta)) * r.iz;
-  // A direction component that is zero (or so small that its reciprocal overflows or nearly does) makes these products
-  // infinite, and a plane distance "finite * inf + (-+inf)" is then an infinity or a NaN depending on the plane's sign --
-  // which would reject boxes the ray runs inside of. On such an axis every plane pair is placed at (-inf, +inf): the axis
-  // never decides, which is conservative.
-  if (!(fabsf(r.ix) < 0x1.0p40f)) { q.sx = 0.0f; q.lx = -INFINITY; q.hx = INFINITY; }
-  if (!(fabsf(r.iy) < 0x1.0p40f)) { q.sy = 0.0f; q.ly = -INFINITY; q.hy = INFINITY; }
-  if (!(fabsf(r.iz) < 0x1.0p40f)) { q.sz = 0.0f; q.lz = -INFINITY; q.hz = INFINITY; }
+  q.sx = ob.grid_step[0] * ix; q.sy = ob.grid_step[1] * iy; q.sz = ob.grid_step[2] * iz;
+  q.lx = (ob.grid_lo[0] - (r.ox + r.delta)) * ix; q.hx = (ob.grid_lo[0] - (r.ox - r.delta)) * ix;
+  q.ly = (ob.grid_lo[1] - (r.oy + r.delta)) * iy; q.hy = (ob.grid_lo[1] - (r.oy - r.delta)) * iy;
+  q.lz = (ob.grid_lo[2] - (r.oz + r.delta)) * iz; q.hz = (ob.grid_lo[2] - (r.oz - r.delta)) * iz;
   return q;
 }
 
@@ -382,6 +383,40 @@ __device__ __forceinline__ Children test_children(const uint4* __restrict__ np, 
   return c;
 }
 
+// RT_NODES_QUAD: the four children of the node at `np` against the ray, then ordered by entry distance. Returns how many
+// the ray meets; ref[0 .. n) are their references, nearest first (the nearest rule walks into ref[0] and stacks the others
+// so that ref[1] is popped next). An unused slot has an inside-out box and the reference RT_REF_NONE; it never counts.
+struct Quad { uint32_t ref[4]; uint32_t n; };
+
+__device__ __forceinline__ Quad test_children4(const uint4* __restrict__ np, const QuantRay& r, float tmax) {
+  const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+  const uint32_t w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+  uint32_t ref[4] = {w3.x, w3.y, w3.z, w3.w};
+  uint32_t key[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    // child c: levels lo.x lo.y | lo.z hi.x | hi.y hi.z in words 3c .. 3c + 2
+    const uint32_t a = w[3 * c], b = w[3 * c + 1], d = w[3 * c + 2];
+    const float ax = __builtin_fmaf(float(a & 0xFFFFu), r.sx, r.lx), bx = __builtin_fmaf(float(b >> 16), r.sx, r.hx);
+    const float ay = __builtin_fmaf(float(a >> 16), r.sy, r.ly), by = __builtin_fmaf(float(d & 0xFFFFu), r.sy, r.hy);
+    const float az = __builtin_fmaf(float(b & 0xFFFFu), r.sz, r.lz), bz = __builtin_fmaf(float(d >> 16), r.sz, r.hz);
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    const bool hit = (tn <= tf * 1.000002f) & (ref[c] != RT_REF_NONE);
+    // tn >= 0 (it is a maximum with 0 that drops NaNs), so its bit pattern orders like its value
+    key[c] = hit ? __float_as_uint(tn) : 0xFFFFFFFFu;
+  }
+  // sorting network for four (key, reference) pairs
+#define RTMI_CSWAP(i, j) do { const bool s_ = key[j] < key[i]; const uint32_t ki_ = s_ ? key[j] : key[i], kj_ = s_ ? key[i] : key[j], \
+                                ri_ = s_ ? ref[j] : ref[i], rj_ = s_ ? ref[i] : ref[j]; key[i] = ki_; key[j] = kj_; ref[i] = ri_; ref[j] = rj_; } while (0)
+  RTMI_CSWAP(0, 1); RTMI_CSWAP(2, 3); RTMI_CSWAP(0, 2); RTMI_CSWAP(1, 3); RTMI_CSWAP(1, 2);
+#undef RTMI_CSWAP
+  Quad q;
+  q.ref[0] = ref[0]; q.ref[1] = ref[1]; q.ref[2] = ref[2]; q.ref[3] = ref[3];
+  q.n = uint32_t(key[0] != 0xFFFFFFFFu) + uint32_t(key[1] != 0xFFFFFFFFu) + uint32_t(key[2] != 0xFFFFFFFFu) + uint32_t(key[3] != 0xFFFFFFFFu);
+  return q;
+}
+
 struct MeshHit { double t, t_raw; uint32_t index; uint32_t slot; };
 
 // Closest hit inside one mesh through its BVH. RULE = RT_HIT_FIRST_INDEX returns the hit
@@ -410,6 +445,14 @@ __device__ __forceinline__ bool mesh_closest(const uint4* __restrict__ nodes, co
       if (COUNT) ++n_nodes;
       // nearest rule: nothing farther than the best hit so far (rounded up, with the same slack) can win
       const float tmax = RULE == RT_HIT_NEAREST ? __double2float_ru(best.t) * 1.000002f : INFINITY;
+      if (FMT == RT_NODES_QUAD) {
+        const Quad c = test_children4(nodes + size_t(cur) * F::kWords4, qr, tmax);
+        if (c.n > 3) stack[(sp++) * kBlock] = c.ref[3];
+        if (c.n > 2) stack[(sp++) * kBlock] = c.ref[2];
+        if (c.n > 1) stack[(sp++) * kBlock] = c.ref[1];
+        cur = c.n ? c.ref[0] : (sp ? stack[(--sp) * kBlock] : kDone);
+        continue;
+      }
       const Children c = test_children<FMT>(nodes + size_t(cur) * F::kWords4, qr, tmax);   // from LDS when the tree is staged
       bool h0 = c.h0, h1 = c.h1;
       if (RULE == RT_HIT_FIRST_INDEX) { h0 = h0 && c.min0 < best.index; h1 = h1 && c.min1 < best.index; }
@@ -531,6 +574,8 @@ __device__ __forceinline__ bool closest_hit(const DevScene& sc, const uint4* __r
         ok = mesh_closest<RT_NODES_SMALL, RULE, COUNT>(node_words + size_t(ob.root) * 2, tris, frames, ob, o, d, dn, stack, mh, n_nodes, n_prims);
       else if (RULE == RT_HIT_NEAREST && sc.node_format == RT_NODES_NEAREST)
         ok = mesh_closest<RT_NODES_NEAREST, RULE, COUNT>(node_words + size_t(ob.root) * 2, tris, frames, ob, o, d, dn, stack, mh, n_nodes, n_prims);
+      else if (RULE == RT_HIT_NEAREST && sc.node_format == RT_NODES_QUAD)
+        ok = mesh_closest<RT_NODES_QUAD, RULE, COUNT>(node_words + size_t(ob.root) * 4, tris, frames, ob, o, d, dn, stack, mh, n_nodes, n_prims);
       else
         ok = mesh_closest<RT_NODES_WIDE, RULE, COUNT>(node_words + size_t(ob.root) * 3, tris, frames, ob, o, d, dn, stack, mh, n_nodes, n_prims);
       t = mh.t; t_raw = mh.t_raw; prim = mh.index; slot = mh.slot;
@@ -1584,6 +1629,17 @@ traverse_kernel(DevScene sc, PathQueue q, MeshList mesh, uint32_t region_entries
           if (COUNT) count_slot(w_nodes);
           if (COUNT) ++n_nodes;
           const float tmax = RULE == RT_HIT_NEAREST ? __double2float_ru(mh.t) * 1.000002f : INFINITY;
+          if (FMT == RT_NODES_QUAD) {
+            // every reference was checked when the tree was built; the bound keeps a damaged one from becoming a wild fetch
+            if (root + cur >= sc.n_nodes) { cur = kDone; sp = 0; continue; }
+            const Quad c = test_children4(node_words + (size_t(root) + cur) * F::kWords4, qr, tmax);
+            const int cap = int(sc.stack_entries);
+            if (c.n > 3 && sp < cap) stack[(sp++) * kBlock] = typename F::stack_t(c.ref[3]);
+            if (c.n > 2 && sp < cap) stack[(sp++) * kBlock] = typename F::stack_t(c.ref[2]);
+            if (c.n > 1 && sp < cap) stack[(sp++) * kBlock] = typename F::stack_t(c.ref[1]);
+            cur = c.n ? c.ref[0] : (sp ? stack[(--sp) * kBlock] : kDone);
+            continue;
+          }
           const Children c = test_children<FMT, RULE == RT_HIT_NEAREST>(node_words + (size_t(root) + cur) * F::kWords4, qr, tmax);
           const uint32_t ref0 = c.ref0, ref1 = c.ref1, min0 = c.min0, min1 = c.min1;
           const float tn0 = c.tn0, tn1 = c.tn1;
@@ -1878,6 +1934,7 @@ void launch_traverse(const DevScene& sc, PathQueue q, MeshList mesh, uint32_t ma
   } while (0)
   const bool nearest = sc.hit_rule == RT_HIT_NEAREST;
   if (sc.node_format == RT_NODES_SMALL) { if (nearest) RTMI_TRAVERSE(RT_NODES_SMALL, 1); else RTMI_TRAVERSE(RT_NODES_SMALL, 0); }
+  else if (nearest && sc.node_format == RT_NODES_QUAD) RTMI_TRAVERSE(RT_NODES_QUAD, 1);
   else if (nearest) RTMI_TRAVERSE(RT_NODES_NEAREST, 1);
   else RTMI_TRAVERSE(RT_NODES_WIDE, 0);
 #undef RTMI_TRAVERSE

@@ -98,13 +98,18 @@ static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 //   RT_NODES_NEAREST (32 bytes; nearest-hit rule only, which never reads the minimum indices)
 //              word 6 = ref0, word 7 = ref1, as in BvhNode
 //   RT_NODES_WIDE    (48 bytes) words 6-9 = ref0, ref1, min_index0, min_index1, as in BvhNode; words 10-11 unused
+//   RT_NODES_QUAD    (64 bytes; nearest-hit rule, large meshes) four children per node, made by pulling grandchildren of
+//              the binary tree up into their grandparent: words 0-11 = the children's boxes, six 16-bit levels each
+//              (lo.x, lo.y, lo.z, hi.x, hi.y, hi.z of child 0, then child 1, 2, 3), words 12-15 = their references as in
+//              BvhNode (RT_REF_NONE for an unused slot). A ray's walk through a large tree waits on a chain of
+//              dependent node fetches; four-wide nodes halve the chain.
 //   With RT_SMALL_F16 the twelve planes of the RT_NODES_SMALL format are binary16 values (coordinate / grid_step, grid_lo = 0,
 //   rounded outward; csrc/bvh_quant.h) in the same positions instead of integer levels.
 #ifndef RT_SMALL_F16
 #define RT_SMALL_F16 1
 #endif
 struct alignas(16) RtWord4 { uint32_t x, y, z, w; };
-enum { RT_NODES_SMALL = 0, RT_NODES_NEAREST = 1, RT_NODES_WIDE = 2 };
+enum { RT_NODES_SMALL = 0, RT_NODES_NEAREST = 1, RT_NODES_WIDE = 2, RT_NODES_QUAD = 3 };
 #define RT_SMALL_MAX_TRIS 8188u
 #define RT_SMALL_LEAF_FLAG 0x8000u
 #define RT_SMALL_REF_NONE 0xFFFFu
@@ -145,6 +150,8 @@ struct DevScene {
   uint32_t lds_nodes;         // > 0: all BVH nodes of the scene (this many 16-byte words) are staged into LDS by every workgroup
   uint32_t node_format;       // RT_NODES_*
   uint32_t extension_materials;  // some material is glossy or dielectric: kernels with that shading code are used
+  uint32_t n_nodes;              // nodes of all meshes together, in nodes of node_format (bounds every node index)
+  uint32_t pad0;
 };
 
 struct DevCamera {

@@ -3,8 +3,8 @@
 Closest hits under both hit rules are compared with the oracle's linear scan on a few thousand fixed rays (all the
 oracle can afford at a million triangle tests per ray); whole renders at 4K are checked through properties that do not
 depend on the size: reproducible bits, sample ranges = interleaved tiles = one call, segment counts that add up, small
-batches = large batches, both node formats a mesh of this size can get (32 bytes under the nearest rule, 48 bytes under
-the first-index rule)."""
+batches = large batches, both node formats a mesh of this size gets by default (32 bytes under the nearest rule, 48 bytes
+under the first-index rule), and the optional four-wide nodes on the same rays."""
 import numpy as np
 import pytest
 
@@ -62,6 +62,19 @@ def test_closest_hits_against_the_linear_scan(ctx, arrays, rule):
     a_ref, _ = osc.trace_batch(rays, O.INT_NORMAL, 0, seed=0)
     assert np.abs(a_gpu - a_ref).max() <= 1e-5
     gsc.close()
+    if rule == O.HIT_NEAREST:      # the optional four-wide nodes (RTMI_NODE_FORMAT=quad) on the same rays
+        import os
+        os.environ["RTMI_NODE_FORMAT"] = "quad"
+        try:
+            qsc = api.Scene(ctx, *arr, hit_rule=rule)
+        finally:
+            del os.environ["RTMI_NODE_FORMAT"]
+        qinfo = qsc.info()
+        assert qinfo["node_bytes"] == qinfo["n_nodes"] * 64 and qinfo["n_nodes"] < 0.6 * info["n_nodes"]
+        assert check_hits(qsc.intersect_batch(rays), ref, "1M-triangle mesh, four-wide nodes") == 1.0
+        q_gpu, _ = qsc.trace_batch(rays, O.INT_NORMAL, 0, seed=0)
+        assert (q_gpu.view(np.uint32) == a_gpu.view(np.uint32)).all()
+        qsc.close()
 
 
 @pytest.mark.parametrize("rule", [O.HIT_NEAREST, O.HIT_FIRST_INDEX])
