@@ -5,7 +5,7 @@ mirror-Suzanne variant of the benchmark configuration.
 
 Bars, per image: 8-bit RMSE <= 0.25 LSB against the oracle's reference-order pipeline (60-bin sums, then XYZ);
 mean XYZ bit-identical on >= 99.9 % of the pixels; path and segment counts equal (seeds are fixed, so both sides are
-deterministic; observed on MI355X: every pixel of all six images bit-identical, RMSE <= 0.003 LSB).
+deterministic; observed on MI355X: every pixel of all seven images bit-identical, RMSE <= 0.003 LSB).
 
 The measured figures are appended to gpurun_out/stock_parity.json when that directory exists, for the results table.
 """
@@ -86,3 +86,9 @@ def test_specular_suzanne(ctx):
     """The mirror-Suzanne variant of the benchmark configuration: reflections off a non-convex mesh under the first-index
     rule, where a slip in the normal flip or the ray offset would show. 640x360 at 32 spp keeps the oracle to seconds."""
     compare(ctx, "scene2 specular mesh", scenes.scene2, O.INT_RANDOM_WALK, 10, 32, seed=3, width=640, height=360, specular_mesh=True)
+
+
+def test_benchmark_configuration_at_full_size(ctx):
+    """The benchmark configuration itself, whole: Suzanne at 1920x1080, 64 spp, depth 10, first-index rule -- 267 M segments
+    through the oracle's linear scans (about 50 s on 16 cores) against one 16 ms step of the library."""
+    compare(ctx, "suzanne 1920x1080x64", scenes.scene2, O.INT_RANDOM_WALK, 10, 64, seed=0, width=1920, height=1080)
