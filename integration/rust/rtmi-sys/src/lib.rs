@@ -38,6 +38,8 @@ pub const RTMI_SPEC_REFLECTANCE: c_int = 0;
 pub const RTMI_SPEC_ILLUMINANT: c_int = 1;
 pub const RTMI_FLAG_TIME_KERNELS: u32 = 1;
 pub const RTMI_FLAG_COUNT_TRAVERSAL: u32 = 2;
+/// This call's share of the render is empty (a rank beyond the samples of a sample partition): nothing is rendered.
+pub const RTMI_FLAG_EMPTY_SHARE: u32 = 4;
 pub const RTMI_SCENE_GPU_BVH: u32 = 1;
 pub const RTMI_PARTITION_SAMPLES: u32 = 0;
 pub const RTMI_PARTITION_TILES: u32 = 1;
