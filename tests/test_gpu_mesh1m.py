@@ -116,3 +116,27 @@ def test_full_size_render_properties(ctx, arrays, rule):
     centre = full.view(H, W, 3)[H // 2 - 200:H // 2 + 200, W // 2 - 200:W // 2 + 200, 1]
     assert float(centre.mean()) > 0.0
     gsc.close()
+
+
+@pytest.mark.parametrize("rule", [O.HIT_NEAREST, O.HIT_FIRST_INDEX])
+def test_image_against_the_oracle_through_its_own_tree(ctx, rule):
+    """Whole paths on the million-triangle mesh: the camera and scene of the 4K configuration through 960x540 pixels, 16 spp,
+    depth 10, against the oracle. A linear scan over a million triangles per segment is out of reach, so the oracle walks
+    its own median-split tree here, which returns the linear scan's hits and paths exactly
+    (tests/test_oracle_semantics.py::test_optional_cpu_bvh_returns_the_linear_scan). Bars as at the stock sizes."""
+    from raytracing_amd import api
+    w, h, spp, depth = 960, 540, 16, 10
+    osc, ocam, _ = S.oracle_scene(scenes.synthetic_mesh_scene, hit_rule=rule, width=w, height=h)
+    osc.enable_bvh()
+    gsc, gcam, _ = S.library_scene(ctx, scenes.synthetic_mesh_scene, hit_rule=rule, width=w, height=h)
+    ref8, _, ref_lin, ref_st = osc.render(ocam, O.INT_RANDOM_WALK, depth, spp, seed=5)
+    gpu8, gpu_xyz, st = gsc.render(gcam, api.render_params(O.INT_RANDOM_WALK, depth, spp, seed=5))
+    gsc.close()
+    diff = gpu8.astype(np.int32) - ref8.astype(np.int32)
+    rmse = float(np.sqrt((diff.astype(np.float64) ** 2).mean()))
+    exact = float((gpu_xyz == ref_lin).all(axis=2).mean())
+    print("1M-triangle image, rule %d: rmse %.4f LSB, %.5f of pixels bit-identical, segments %d / %d, oracle %.1f s"
+          % (rule, rmse, exact, st["segments"], ref_st.segments, ref_st.seconds))
+    assert ref8.any() and rmse <= 0.25 and exact >= 0.999
+    assert st["paths"] == ref_st.paths == w * h * spp
+    assert st["segments"] == ref_st.segments

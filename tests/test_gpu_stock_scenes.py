@@ -36,10 +36,10 @@ def ctx():
     c.close()
 
 
-def compare(ctx, what, recipe, integrator, depth, spp, seed, **kw):
+def compare(ctx, what, recipe, integrator, depth, spp, seed, hit_rule=O.HIT_FIRST_INDEX, **kw):
     from raytracing_amd import api
-    osc, ocam, _ = S.oracle_scene(recipe, **kw)
-    gsc, gcam, _ = S.library_scene(ctx, recipe, **kw)
+    osc, ocam, _ = S.oracle_scene(recipe, hit_rule=hit_rule, **kw)
+    gsc, gcam, _ = S.library_scene(ctx, recipe, hit_rule=hit_rule, **kw)
     ref8, _, ref_lin, ref_st = osc.render(ocam, integrator, depth, spp, seed=seed, threads=ORACLE_THREADS)
     gpu8, gpu_xyz, st = gsc.render(gcam, api.render_params(integrator, depth, spp, seed=seed))
     gsc.close()
@@ -86,6 +86,12 @@ def test_specular_suzanne(ctx):
     """The mirror-Suzanne variant of the benchmark configuration: reflections off a non-convex mesh under the first-index
     rule, where a slip in the normal flip or the ray offset would show. 640x360 at 32 spp keeps the oracle to seconds."""
     compare(ctx, "scene2 specular mesh", scenes.scene2, O.INT_RANDOM_WALK, 10, 32, seed=3, width=640, height=360, specular_mesh=True)
+
+
+def test_suzanne_under_the_nearest_rule(ctx):
+    """The library's other hit rule (the closest triangle inside a mesh, an extension: the reference takes the first in file
+    order) on scene2.toml's scene at 640x360, 32 spp."""
+    compare(ctx, "scene2 nearest rule", scenes.scene2, O.INT_RANDOM_WALK, 10, 32, seed=4, hit_rule=O.HIT_NEAREST, width=640, height=360)
 
 
 def test_benchmark_configuration_at_full_size(ctx):
