@@ -211,6 +211,19 @@ static inline void aabb_union(v3* mn, v3* mx, v3 omn, v3 omx) {
   *mx = v3_make(fmax(mx->x, omx.x), fmax(mx->y, omx.y), fmax(mx->z, omx.z));
 }
 
+/* AABB::new(p_1, p_2) followed by AABB::union(&other) -- the pair ModelObj::new folds over its triangles' boxes
+ * (geometry/aabb.rs:26-61, shapes/model_obj.rs:62-66); resize_box (aabb.rs:77-79) is the same union in place. */
+void ref_aabb_new(const double p1[3], const double p2[3], double bmin[3], double bmax[3]) {
+  v3 mn, mx;
+  aabb_new(v3_from(p1), v3_from(p2), &mn, &mx);
+  v3_to(mn, bmin); v3_to(mx, bmax);
+}
+void ref_aabb_union(const double amin[3], const double amax[3], const double bmin[3], const double bmax[3], double omin[3], double omax[3]) {
+  v3 mn = v3_from(amin), mx = v3_from(amax);
+  aabb_union(&mn, &mx, v3_from(bmin), v3_from(bmax));
+  v3_to(mn, omin); v3_to(mx, omax);
+}
+
 /* ------------------------------------- cosine hemisphere sampling (geometry/mod.rs:85-116) */
 
 void ref_random_versor_cos_density(const double n[3], double r1, double r2, double out[3]) {

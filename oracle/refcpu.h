@@ -117,6 +117,9 @@ int  ref_ray_at(const ref_ray* r, double t, double out[3]);
 void ref_affine_ray(const ref_affine* a, const ref_ray* r, ref_ray* out);
 int  ref_intersect_ray_and_triangle(const double v[9], const ref_ray* r, double tuv[3]);
 int  ref_aabb_intersect_ray(const double bmin[3], const double bmax[3], const ref_ray* r, double* t);
+void ref_aabb_new(const double p1[3], const double p2[3], double bmin[3], double bmax[3]);                 /* aabb.rs:26-39 */
+void ref_aabb_union(const double amin[3], const double amax[3], const double bmin[3], const double bmax[3],
+                    double omin[3], double omax[3]);                                                      /* aabb.rs:49-61, 77-79 */
 void ref_random_versor_cos_density(const double n[3], double r1, double r2, double out[3]);
 
 /* shapes (src/shapes/) */

@@ -112,6 +112,10 @@ def lib():
     L.ref_affine_ray.argtypes = [C.POINTER(Affine), C.POINTER(Ray), C.POINTER(Ray)]
     L.ref_intersect_ray_and_triangle.argtypes = [d3, C.POINTER(Ray), d3]
     L.ref_aabb_intersect_ray.argtypes = [d3, d3, C.POINTER(Ray), d3]
+    L.ref_aabb_new.argtypes = [d3, d3, d3, d3]
+    L.ref_aabb_new.restype = None
+    L.ref_aabb_union.argtypes = [d3, d3, d3, d3, d3, d3]
+    L.ref_aabb_union.restype = None
     L.ref_random_versor_cos_density.argtypes = [d3, C.c_double, C.c_double, d3]
     L.ref_phong_lobe_direction.argtypes = [d3, C.c_double, C.c_double, C.c_double, d3]
     L.ref_dielectric_direction.restype = C.c_int

@@ -163,6 +163,26 @@ def test_aabb(oracle):
     assert aabb_hit(oracle, (0, 0, 0), (2, 2, 2), (1, 1, 1), (1, 0, 0))            # rayo_adentro_de_caja :282
 
 
+def aabb_box(o, p1, p2):
+    lo, hi = o.vec3(0, 0, 0), o.vec3(0, 0, 0)
+    o.lib().ref_aabb_new(o.vec3(*p1), o.vec3(*p2), lo, hi)
+    return lo, hi
+
+
+def test_aabb_union(oracle):
+    """unir_cajas :295 and ampliar_caja :308 (resize_box is the union in place, aabb.rs:77-79): the fold ModelObj::new runs
+    over its triangles' boxes to get the box every mesh ray is tested against first (shapes/model_obj.rs:62-66,78)."""
+    c1, c2 = aabb_box(oracle, (1, 1, 1), (2, 2, 2)), aabb_box(oracle, (0, 0, 0), (1, 1, 1))
+    lo, hi = oracle.vec3(0, 0, 0), oracle.vec3(0, 0, 0)
+    oracle.lib().ref_aabb_union(c1[0], c1[1], c2[0], c2[1], lo, hi)
+    assert close(list(lo), (0, 0, 0)) and close(list(hi), (2, 2, 2))
+    oracle.lib().ref_aabb_union(c1[0], c1[1], c2[0], c2[1], c1[0], c1[1])          # in place, as resize_box
+    assert close(list(c1[0]), (0, 0, 0)) and close(list(c1[1]), (2, 2, 2))
+    # AABB::new orders its corners (aabb.rs:26-39)
+    lo, hi = aabb_box(oracle, (2, 0, 5), (1, 3, 4))
+    assert list(lo) == [1, 0, 4] and list(hi) == [2, 3, 5]
+
+
 # ---- src/shapes/triangle.rs:110-133 (the :136 test is wrong upstream: 90.0 is radians there)
 
 def test_triangle_intersects_ray(oracle):
