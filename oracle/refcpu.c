@@ -201,6 +201,10 @@ int ref_aabb_intersect_ray(const double bmin[3], const double bmax[3], const ref
   return aabb_hit(v3_from(bmin), v3_from(bmax), rayi_from(r), t);
 }
 
+/* src/auxiliar.rs:1-9 (used by Triangle::get_box, shapes/triangle.rs:44-54) */
+double ref_smaller_of_three(double a, double b, double c) { return fmin(a, fmin(b, c)); }
+double ref_bigger_of_three(double a, double b, double c) { return fmax(a, fmax(b, c)); }
+
 /* AABB::new / union (geometry/aabb.rs:26-61) */
 static inline void aabb_new(v3 a, v3 b, v3* mn, v3* mx) {
   *mn = v3_make(fmin(a.x, b.x), fmin(a.y, b.y), fmin(a.z, b.z));
@@ -619,8 +623,8 @@ ref_scene* ref_scene_create(const ref_scene_desc* d) {
         const double* v = s->triangles[o->first + k].v;
         v3 p1 = v3_from(v), p2 = v3_from(v + 3), p3 = v3_from(v + 6), mn, mx;
         /* Triangle::get_box triangle.rs:35-57 (identity map) */
-        v3 lo = v3_make(fmin(p1.x, fmin(p2.x, p3.x)), fmin(p1.y, fmin(p2.y, p3.y)), fmin(p1.z, fmin(p2.z, p3.z)));
-        v3 hi = v3_make(fmax(p1.x, fmax(p2.x, p3.x)), fmax(p1.y, fmax(p2.y, p3.y)), fmax(p1.z, fmax(p2.z, p3.z)));
+        v3 lo = v3_make(ref_smaller_of_three(p1.x, p2.x, p3.x), ref_smaller_of_three(p1.y, p2.y, p3.y), ref_smaller_of_three(p1.z, p2.z, p3.z));
+        v3 hi = v3_make(ref_bigger_of_three(p1.x, p2.x, p3.x), ref_bigger_of_three(p1.y, p2.y, p3.y), ref_bigger_of_three(p1.z, p2.z, p3.z));
         aabb_new(lo, hi, &mn, &mx);
         aabb_union(&a->bmin, &a->bmax, mn, mx);
       }

@@ -117,6 +117,8 @@ int  ref_ray_at(const ref_ray* r, double t, double out[3]);
 void ref_affine_ray(const ref_affine* a, const ref_ray* r, ref_ray* out);
 int  ref_intersect_ray_and_triangle(const double v[9], const ref_ray* r, double tuv[3]);
 int  ref_aabb_intersect_ray(const double bmin[3], const double bmax[3], const ref_ray* r, double* t);
+double ref_smaller_of_three(double a, double b, double c);   /* src/auxiliar.rs:2-4 */
+double ref_bigger_of_three(double a, double b, double c);    /* src/auxiliar.rs:7-9 */
 void ref_aabb_new(const double p1[3], const double p2[3], double bmin[3], double bmax[3]);                 /* aabb.rs:26-39 */
 void ref_aabb_union(const double amin[3], const double amax[3], const double bmin[3], const double bmax[3],
                     double omin[3], double omax[3]);                                                      /* aabb.rs:49-61, 77-79 */

@@ -112,6 +112,9 @@ def lib():
     L.ref_affine_ray.argtypes = [C.POINTER(Affine), C.POINTER(Ray), C.POINTER(Ray)]
     L.ref_intersect_ray_and_triangle.argtypes = [d3, C.POINTER(Ray), d3]
     L.ref_aabb_intersect_ray.argtypes = [d3, d3, C.POINTER(Ray), d3]
+    for f in (L.ref_smaller_of_three, L.ref_bigger_of_three):
+        f.argtypes = [C.c_double] * 3
+        f.restype = C.c_double
     L.ref_aabb_new.argtypes = [d3, d3, d3, d3]
     L.ref_aabb_new.restype = None
     L.ref_aabb_union.argtypes = [d3, d3, d3, d3, d3, d3]

@@ -163,6 +163,13 @@ def test_aabb(oracle):
     assert aabb_hit(oracle, (0, 0, 0), (2, 2, 2), (1, 1, 1), (1, 0, 0))            # rayo_adentro_de_caja :282
 
 
+def test_smaller_and_bigger_of_three(oracle):  # src/auxiliar.rs:54,63 (the corners of a triangle's box, shapes/triangle.rs:44-54)
+    a, b, c = 1.0, 2.0, 3.0
+    lo, hi = oracle.lib().ref_smaller_of_three, oracle.lib().ref_bigger_of_three
+    assert abs(lo(a, b, c) - a) < TOL and abs(lo(c, b, a) - a) < TOL and abs(lo(b, a, c) - a) < TOL
+    assert abs(hi(a, b, c) - c) < TOL and abs(hi(c, b, a) - c) < TOL and abs(hi(b, c, a) - c) < TOL
+
+
 def aabb_box(o, p1, p2):
     lo, hi = o.vec3(0, 0, 0), o.vec3(0, 0, 0)
     o.lib().ref_aabb_new(o.vec3(*p1), o.vec3(*p2), lo, hi)
