@@ -98,3 +98,23 @@ def test_benchmark_configuration_at_full_size(ctx):
     """The benchmark configuration itself, whole: Suzanne at 1920x1080, 64 spp, depth 10, first-index rule -- 267 M segments
     through the oracle's linear scans (about 50 s on 16 cores) against one 16 ms step of the library."""
     compare(ctx, "suzanne 1920x1080x64", scenes.scene2, O.INT_RANDOM_WALK, 10, 64, seed=0, width=1920, height=1080)
+
+
+@pytest.mark.parametrize("name,recipe,rule", [("scene.toml", scenes.scene1, O.HIT_FIRST_INDEX), ("scene2.toml", scenes.scene2, O.HIT_FIRST_INDEX),
+                                              ("scene2.toml, nearest rule", scenes.scene2, O.HIT_NEAREST), ("scene3.toml", scenes.scene3, O.HIT_FIRST_INDEX)])
+def test_a_million_random_rays(ctx, name, recipe, rule):
+    """Scene::intersect_ray (src/scene.rs:135-150) on 2^20 seeded rays from a sphere around each stock scene towards points
+    near its centre: object and triangle ids equal on every ray, t / point / normal to the bit (for Suzanne that is a
+    thousand million Moller-Trumbore tests on the oracle's side, about 10 s on 16 cores)."""
+    from test_gpu_parity import check_hits
+    osc, _, _ = S.oracle_scene(recipe, hit_rule=rule)
+    gsc, _, _ = S.library_scene(ctx, recipe, hit_rule=rule)
+    rays = S.random_rays(1 << 20, seed=2026, center=(0.0, 0.0, 0.5), radius=2.8 if recipe is scenes.scene1 else 6.0, spread=1.5)
+    gpu = gsc.intersect_batch(rays)
+    ref = osc.intersect_batch(rays, threads=ORACLE_THREADS)
+    gsc.close()
+    assert check_hits(gpu, ref, name + ", 2^20 random rays") == 1.0
+    hit = ref["obj"] != O.MISS
+    assert 0.05 < hit.mean() < 1.0 or recipe is scenes.scene1      # scene.toml's rays start inside its closed room: every one hits
+    same_bits = (gpu["t"].view(np.uint64) == ref["t"].view(np.uint64))[hit].mean()
+    print("%s: 2^20 rays, %d hits, ids equal on all, t bit-identical on %.6f" % (name, int(hit.sum()), same_bits))
