@@ -342,6 +342,9 @@ def main():
                     help="one process, this many GPUs behind the C ABI (rtmi_multi_render: partition + ncclReduce inside the library) "
                          "instead of one process per GPU; prints the same line with backend \"rtmi_multi\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustain", type=float, default=8.0,
+                    help="after the timed steps, keep stepping for about this many seconds and report the rate over that stretch too "
+                         "(`sustained`: clocks settled, and long enough for an outside utilisation sampler to see it); 0 = skip")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every core this process may use)")
     ap.add_argument("--batch-paths", type=int, default=0, help="path slots per batch of launches (0 = library default)")
     ap.add_argument("--gpu-bvh", action="store_true", help="build the meshes' trees on the GPU (Morton order + radix tree) instead of the host SAH build")
@@ -460,6 +463,22 @@ def main():
         elapsed = float(tmax[0])
     total_segments, total_mesh_rays = float(t[1]), float(t[2])
 
+    # untimed as far as `value` goes: the same step for several seconds on end. `elapsed` is already the maximum over the
+    # ranks, so every rank arrives at the same number of steps (the merge inside a step is a collective).
+    sustained = None
+    if args.sustain > 0:
+        n_sus = max(1, min(20000, int(args.sustain * args.steps / max(elapsed, 1e-9))))
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        fence()
+        sus = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device=stats_device)
+        if world > 1:
+            dist.all_reduce(sus, op=dist.ReduceOp.MAX)
+        sustained = {"seconds": float(sus[0]), "steps": n_sus, "ms_per_step": float(sus[0]) / n_sus * 1e3,
+                     "value": total_segments / args.steps * n_sus / float(sus[0]) / 1e6, "unit": "Mseg/s"}
+
     if rank == 0:
         info = scene.info()
         out = {
@@ -486,6 +505,7 @@ def main():
             "backend": dist.get_backend() if world > 1 else None,
             "per_rank_ms_per_step": per_rank_ms,
             "ms_per_step_instrumented": instrumented_ms,
+            "sustained": sustained,
             "roofline": roofline(args, w, info, counted, timed, world),
             "cpu_baseline": cpu,
         }

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def _run(extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", "scene1_400x225_100spp", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600, env=env)
+                        "--no-cpu-baseline", "--sustain", "0.3"] + extra, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -29,6 +29,10 @@ def test_two_ranks_on_one_gpu_by_samples_and_by_tiles():
     two = _run(["--gpus", "2", "--share-gpu"])
     assert two["n_gpus"] == 2 and two["world_size"] == 2 and two["backend"] == "gloo"
     assert len(two["per_rank_ms_per_step"]) == 2 and all(ms > 0 for ms in two["per_rank_ms_per_step"])
+    # the sustained leg: the same step for a stated stretch after the timed ones (every rank takes the same number of steps)
+    for line in (one, two):
+        sus = line["sustained"]
+        assert sus["steps"] >= 1 and 0.0 < sus["ms_per_step"] < 50 * line["ms_per_step"] and sus["value"] > 0
     assert two["scaling"] == "weak" and two["config"]["spp_job"] == 2 * one["config"]["spp_job"]
     # weak scaling in samples: the job has twice the paths; its segment count is within a per cent of twice one rank's
     seg1 = one["config"]["segments_per_step_per_gpu"]

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 for v in "$@"; do
   if [ "$v" = base ]; then unset RTMI_LIB; else export RTMI_LIB=raytracing_amd/librtmi_$v.so; fi
   rm -rf /tmp/abt_$v
-  timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abt_$v -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 $args > /tmp/abt_$v.log 2>&1
+  timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abt_$v -- python3 bench.py --no-cpu-baseline --sustain 0 --steps 3 --warmup 1 $args > /tmp/abt_$v.log 2>&1
   echo "== $v"
   python3 - /tmp/abt_$v <<'PY'
 import csv, glob, sys

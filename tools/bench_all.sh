@@ -1,7 +1,7 @@
 #!/bin/bash
 # One line per workload / hit rule: tools/bench_all.sh [extra bench args]
 run() { # workload rule
-  out=$(timeout -k 10 400 python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 --workload $1 --rule $2 "${@:3}" 2>/dev/null | grep '^{' | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); r=d["roofline"]; print("%9.1f Mseg/s %8.2f ms/step  %s avg %.3f ms  nodes %.2f tris %.2f  bvh %.2f s" % (d["value"], d["ms_per_step"], r["kernel"], r["avg_launch_ms"], r["nodes_per_unit"], r["triangles_per_unit"], d["config"]["bvh_build_s"]))')
+  out=$(timeout -k 10 400 python3 bench.py --no-cpu-baseline --sustain 0 --steps 5 --warmup 2 --workload $1 --rule $2 "${@:3}" 2>/dev/null | grep '^{' | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); r=d["roofline"]; print("%9.1f Mseg/s %8.2f ms/step  %s avg %.3f ms  nodes %.2f tris %.2f  bvh %.2f s" % (d["value"], d["ms_per_step"], r["kernel"], r["avg_launch_ms"], r["nodes_per_unit"], r["triangles_per_unit"], d["config"]["bvh_build_s"]))')
   printf "%-32s %-12s %s\n" $1 $2 "$out"
 }
 run suzanne_1080p_64spp first_index "$@"

@@ -9,7 +9,7 @@ python3 tools/source_hash.py > "$out/source_hash.txt"    # what was profiled: be
 export TMPDIR=/tmp
 run() { # name, rocprof args...
   local name=$1; shift
-  timeout -s KILL 300 rocprofv3 "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1
+  timeout -s KILL 300 rocprofv3 "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --sustain 0 "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1
   local rc=$?
   echo "$name exit=$rc"
   return $rc

@@ -8,7 +8,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 run() {
   local name=$1; shift
-  timeout -s KILL 300 rocprofv3 "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1
+  timeout -s KILL 300 rocprofv3 "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --sustain 0 "${BENCH_ARGS[@]}" > "$out/$name.log" 2>&1
   local rc=$?
   echo "$name exit=$rc"
   return $rc

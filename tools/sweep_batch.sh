@@ -4,7 +4,7 @@
 args=$1; shift
 for lg in "$@"; do
   for pipe in split fused; do
-    out=$(RTMI_PIPELINE=$pipe timeout -k 10 300 python3 bench.py $args --no-cpu-baseline --batch-paths $((1 << lg)) 2>&1 | tail -1) || { echo "$pipe 2^$lg failed: $out"; exit 1; }
+    out=$(RTMI_PIPELINE=$pipe timeout -k 10 300 python3 bench.py $args --no-cpu-baseline --sustain 0 --batch-paths $((1 << lg)) 2>&1 | tail -1) || { echo "$pipe 2^$lg failed: $out"; exit 1; }
     python3 - "$pipe" "$lg" "$out" <<'PY'
 import json, sys
 d = json.loads(sys.argv[3])
